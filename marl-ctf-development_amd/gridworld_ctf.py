@@ -1,0 +1,409 @@
+"""Host-side mirror of the reference's ``GridworldCtf`` (reference gridworld_ctf.py:13) over the C ABI.
+
+Two classes:
+
+``VecGridworldCtf``  E independent envs resident in HBM, stepped and rendered by HIP kernels; all I/O is
+                     torch CUDA tensors handed to the C ABI as raw device pointers on the caller's
+                     current HIP stream.  This is the fast path.
+``GridworldCtf``     the reference's single-env API (same constructor kwargs, methods, attributes and
+                     exceptions) as a batch of one, so ``ppo.py`` / ``utils.duel`` / the ``0_..8_*.py``
+                     scripts run against it unchanged (put this directory first on sys.path).
+
+There is no CPU fallback: without the HIP library and a GPU, construction raises.
+"""
+import ctypes as C
+import random as _py_random
+from collections import defaultdict
+from functools import partial
+
+import numpy as np
+
+try:
+    from . import _abi, config as _config
+except ImportError:  # pragma: no cover - this directory itself on sys.path (drop-in use)
+    import _abi
+    import config as _config
+
+__all__ = ["GridworldCtf", "VecGridworldCtf"]
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _as_seed_array(seeds, n):
+    if seeds is None:
+        seeds = np.arange(n, dtype=np.uint64)
+    arr = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(-1))
+    if arr.shape[0] != n:
+        raise ValueError(f"need {n} seeds, got {arr.shape[0]}")
+    return arr
+
+
+class VecGridworldCtf:
+    """``n_envs`` GridworldCtf instances on one MI355X.
+
+    Env ``e`` reproduces, bit for bit, a reference process that ran
+    ``random.seed(py_seeds[e]); np.random.seed(np_seeds[e])`` before constructing its env and was fed
+    the same actions.  Outputs live in tensors owned by this object and are overwritten by the next call.
+    """
+
+    def __init__(self, n_envs, device=None, py_seeds=None, np_seeds=None, log_metrics=True, **env_kwargs):
+        torch = _torch()
+        self._lib = _abi.load_library()
+        self.cfg, self.derived = _config.build_config(env_kwargs, log_metrics=log_metrics)
+        if not torch.cuda.is_available():
+            raise _abi.CtfLibraryError("no HIP device visible: the GridworldCtf kernels need a GPU (there is no CPU fallback)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self.n_envs = int(n_envs)
+        d = self.derived
+        self.N_AGENTS, self.GRID_SIZE = d["n_agents"], d["grid_size"]
+        self.N_CHANNELS, self.META_LEN = self.cfg.n_channels, 2 * d["n_agents"] + 6
+        self.AGENT_TEAMS, self.AGENT_TYPES = d["agent_teams"], d["agent_types"]
+        self.TILES_USED = d["tiles_used"]
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream()  # make sure torch has initialised HIP on this device first
+            h = C.c_void_p()
+            _abi.check(self._lib.ctf_create(C.byref(self.cfg), self.n_envs, self.device.index, C.byref(h)), self._lib)
+        self._h = h
+        E, N = self.n_envs, self.N_AGENTS
+        self.rewards = torch.zeros((E, N), dtype=torch.float32, device=self.device)
+        self.rewards64 = torch.zeros((E, N), dtype=torch.float64, device=self.device)
+        self.done = torch.zeros((E,), dtype=torch.uint8, device=self.device)
+        self.obs = torch.zeros((E, N, self.N_CHANNELS, self.GRID_SIZE, self.GRID_SIZE), dtype=torch.uint8, device=self.device)
+        self.meta = torch.zeros((E, N, self.META_LEN), dtype=torch.float16, device=self.device)
+        self.seed(py_seeds, np_seeds)
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ctf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check_dev(self, t, dtype, numel):
+        torch = _torch()
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == self.device and t.dtype == dtype
+                and t.is_contiguous() and t.numel() == numel):
+            raise ValueError(f"expected a contiguous {dtype} tensor of {numel} elements on {self.device}")
+        return C.c_void_p(t.data_ptr())
+
+    # -- RNG ----------------------------------------------------------------------------------
+    def seed(self, py_seeds=None, np_seeds=None):
+        py = _as_seed_array(py_seeds, self.n_envs)
+        npz = _as_seed_array(np_seeds if np_seeds is not None else py_seeds, self.n_envs)
+        if (npz >> np.uint64(32)).any():
+            raise ValueError("Seed must be between 0 and 2**32 - 1")  # np.random.seed's own message
+        _abi.check(self._lib.ctf_seed(self._h, py.ctypes.data_as(C.c_void_p), npz.ctypes.data_as(C.c_void_p), self._stream()), self._lib)
+        _torch().cuda.current_stream(self.device).synchronize()  # host seed arrays may go away
+
+    def set_rng_state(self, env_index, py_mt625=None, np_mt625=None):
+        a = None if py_mt625 is None else np.ascontiguousarray(py_mt625, dtype=np.uint32)
+        b = None if np_mt625 is None else np.ascontiguousarray(np_mt625, dtype=np.uint32)
+        _abi.check(self._lib.ctf_set_rng_state(self._h, env_index, None if a is None else a.ctypes.data_as(C.c_void_p),
+                                               None if b is None else b.ctypes.data_as(C.c_void_p)), self._lib)
+
+    def get_rng_state(self, env_index):
+        a, b = np.zeros(625, np.uint32), np.zeros(625, np.uint32)
+        _abi.check(self._lib.ctf_get_rng_state(self._h, env_index, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), self._lib)
+        return a, b
+
+    # -- the hot path -------------------------------------------------------------------------
+    def reset(self, mask=None):
+        ptr = None if mask is None else self._check_dev(mask, _torch().uint8, self.n_envs)
+        _abi.check(self._lib.ctf_reset(self._h, ptr, self._stream()), self._lib)
+
+    def step(self, actions, auto_reset=False, want_f64=False):
+        """actions: int8 CUDA tensor [E, N].  -> (rewards float32 [E, N], done uint8 [E]) (views of
+        this object's buffers).  With want_f64 the float64 rewards are also written to ``rewards64``."""
+        a = self._check_dev(actions, _torch().int8, self.n_envs * self.N_AGENTS)
+        _abi.check(self._lib.ctf_step(self._h, a, C.c_void_p(self.rewards.data_ptr()),
+                                      C.c_void_p(self.rewards64.data_ptr()) if want_f64 else None,
+                                      C.c_void_p(self.done.data_ptr()), _abi.STEP_AUTO_RESET if auto_reset else 0,
+                                      self._stream()), self._lib)
+        return self.rewards, self.done
+
+    def observe(self, reverse_mask=None, obs=True, meta=True):
+        """-> (obs uint8 [E, N, C, G, G], meta float16 [E, N, 2N+6]).  ``reverse_mask`` bit i = reverse_grid
+        for agent i (default: team(i) == 1, what every caller in the reference passes)."""
+        rm = _abi.REVERSE_DEFAULT if reverse_mask is None else int(reverse_mask) & ((1 << self.N_AGENTS) - 1)
+        _abi.check(self._lib.ctf_observe(self._h, C.c_void_p(self.obs.data_ptr()) if obs else None,
+                                         C.c_void_p(self.meta.data_ptr()) if meta else None, rm, self._stream()), self._lib)
+        return self.obs, self.meta
+
+    def step_observe(self, actions, auto_reset=False, want_f64=False, reverse_mask=None):
+        """step() then observe() in one call -> (rewards, done, obs, meta)."""
+        a = self._check_dev(actions, _torch().int8, self.n_envs * self.N_AGENTS)
+        rm = _abi.REVERSE_DEFAULT if reverse_mask is None else int(reverse_mask) & ((1 << self.N_AGENTS) - 1)
+        _abi.check(self._lib.ctf_step_observe(self._h, a, C.c_void_p(self.rewards.data_ptr()),
+                                              C.c_void_p(self.rewards64.data_ptr()) if want_f64 else None,
+                                              C.c_void_p(self.done.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                              C.c_void_p(self.meta.data_ptr()), rm,
+                                              _abi.STEP_AUTO_RESET if auto_reset else 0, self._stream()), self._lib)
+        return self.rewards, self.done, self.obs, self.meta
+
+    def random_actions(self, out, seed, step, env_offset=0):
+        """Fill ``out`` (int8 [E, N]) with the synthetic Philox action stream of bench.py / the tests."""
+        a = self._check_dev(out, _torch().int8, self.n_envs * self.N_AGENTS)
+        _abi.check(self._lib.ctf_random_actions(self._h, a, int(seed), int(step), int(env_offset), self._stream()), self._lib)
+        return out
+
+    def action_mask(self):
+        """uint8 [N, 9]: 1 where the action is legal for the agent's type (agent_network.py:66-75)."""
+        m = np.zeros((self.N_AGENTS, _abi.N_ACTIONS), np.uint8)
+        _abi.check(self._lib.ctf_action_mask(self._h, m.ctypes.data_as(C.c_void_p)), self._lib)
+        return m
+
+    # -- host views ---------------------------------------------------------------------------
+    def get_state(self, env_index):
+        v = _abi.CtfStateView()
+        _abi.check(self._lib.ctf_get_state(self._h, int(env_index), C.byref(v)), self._lib)
+        return v
+
+    def set_state(self, env_index, view):
+        _abi.check(self._lib.ctf_set_state(self._h, int(env_index), C.byref(view)), self._lib)
+
+    def status(self):
+        bits = C.c_uint32(0)
+        _abi.check(self._lib.ctf_status(self._h, C.byref(bits), self._stream()), self._lib)
+        return bits.value
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's single-env API
+# ----------------------------------------------------------------------------------------------
+# REVERSED_ACTION_MAP (gridworld_ctf.py:147-196) written as permutations of 0..8:
+#   None: both axes flipped, 0: rows flipped, 1: columns flipped, 2: anti-diagonal reflection
+_REVERSED_ACTIONS = {
+    None: (1, 0, 3, 2, 4, 6, 5, 8, 7),
+    0: (1, 0, 2, 3, 4, 6, 5, 7, 8),
+    1: (0, 1, 3, 2, 4, 5, 6, 8, 7),
+    2: (2, 3, 0, 1, 4, 7, 8, 5, 6),
+}
+_UNIT_MOVES = ((-1, 0), (1, 0), (0, 1), (0, -1), (0, 0))
+
+
+def _action_deltas():
+    table = {}
+    for typ, reach in ((0, 0), (1, 0), (2, 2), (3, 1)):  # scout, guardian, vaulter (jumps 2), miner (acts at 1)
+        table[typ] = {a: _UNIT_MOVES[a] for a in range(5)}
+        for a in range(5, 9):
+            dr, dc = _UNIT_MOVES[a - 5]
+            table[typ][a] = (dr * reach, dc * reach)
+    return table
+
+
+class GridworldCtf:
+    """Drop-in for the reference class, backed by the HIP kernels (a batch of one env).
+
+    ``rng="global"`` (default) keeps the reference's RNG contract exactly: every ``step`` consumes
+    from the process-global ``random`` and ``np.random`` generators (their MT19937 states are handed
+    to the device before the step and written back after it), so ``random.seed(s); np.random.seed(s)``
+    in the caller has the effect it has on the reference.  ``rng="device"`` keeps private streams on
+    the device (seeded with ``seed=``) and avoids the two 2.5 KB transfers per step.
+    """
+
+    def __init__(self, rng="global", seed=0, device=None, **kwargs):
+        self._ctor = dict(rng=rng, seed=seed, device=device, kwargs=dict(kwargs))
+        self._vec = VecGridworldCtf(1, device=device, py_seeds=[seed], np_seeds=[seed], **kwargs)
+        self._rng_mode = rng
+        d = self._vec.derived
+        kw = d["kwargs"]
+        # attributes the reference exposes (gridworld_ctf.py:58-290)
+        self.AGENT_CONFIG, self.SCENARIO = kw["AGENT_CONFIG"], kw["SCENARIO"]
+        self.GAME_STEPS = kw["GAME_STEPS"]
+        self.ENABLE_OBSTACLES, self.DROP_FLAG_WHEN_NO_HP = kw["ENABLE_OBSTACLES"], kw["DROP_FLAG_WHEN_NO_HP"]
+        self.HOME_FLAG_CAPTURE, self.USE_EASY_CAPTURE = kw["HOME_FLAG_CAPTURE"], kw["USE_EASY_CAPTURE"]
+        self.USE_ADJUSTED_REWARDS, self.MAX_BLOCK_TILE_PCT = kw["USE_ADJUSTED_REWARDS"], kw["MAX_BLOCK_TILE_PCT"]
+        self.LOG_METRICS, self.MAP_SYMMETRY_CHECK = kw["LOG_METRICS"], kw["MAP_SYMMETRY_CHECK"]
+        self.N_AGENTS = d["n_agents"]
+        self.ACTION_SPACE = 8
+        self.ENV_DIMS = (1, 1, kw["GRID_SIZE"], kw["GRID_SIZE"])
+        self.WIN_MARGIN_SCALAR, self.LOSS_MARGIN_SCALAR = 0.1, 0.00
+        self.REWARD_CAPTURE, self.REWARD_STEP, self.REWARD_TAG = 1, 0, 0.0
+        self.OPP_FLAG_CAPTURE_PUNISHMENT_SCALAR = 0.5
+        self.WINNING_POINTS = np.inf
+        self.DEFENSIVE_ZONE_DISTANCE = 3
+        self.ACTION_DELTAS = _action_deltas()
+        self.REVERSED_ACTION_MAP = {k: dict(enumerate(v)) for k, v in _REVERSED_ACTIONS.items()}
+        self.AGENT_TEAMS, self.AGENT_TYPES = d["agent_teams"], d["agent_types"]
+        self.AGENT_TYPE_HP, self.AGENT_HP_HEALING_PER_STEP = kw["AGENT_TYPE_HP"], kw["AGENT_HP_HEALING_PER_STEP"]
+        self.AGENT_TYPE_DAMAGE = kw["AGENT_TYPE_DAMAGE"]
+        self.AGENT_TYPE_ACTION_MASK = {0: 1, 1: 1, 2: 0, 3: 0}
+        self.GUARDIAN_DEFENSE_DISTANCE, self.GUARDIAN_TAGGING_RANGE = 3, 1
+        self.GUARDIAN_DAMAGE_MULTIPLIER, self.TAG_PROBABILITY = kw["GUARDIAN_DAMAGE_MULTIPLIER"], kw["TAG_PROBABILITY"]
+        self.VAULT_HP_COST, self.VAULT_MIN_HP = kw["VAULT_HP_COST"], kw["VAULT_MIN_HP"]
+        self.AGENT_FLAG_CAPTURE_TYPES = [0, 1, 2, 3]
+        self.MAX_AGENT_BLOCKS = 1000
+        self.OPEN_TILE, self.BLOCK_TILE, self.DESTRUCTIBLE_TILE1, self.DESTRUCTIBLE_TILE2 = 0, 1, 2, 3
+        self.AGENT_TYPE_TILE_MAP = _config.AGENT_TYPE_TILE_MAP
+        self.AGENT_TILE_MAP = d["agent_tile_map"]
+        self.FLAG_TILE_MAP = dict(_config.FLAG_TILE_MAP)
+        self.STD_OWN_FLAG_TILE, self.STD_OPP_FLAG_TILE = 12, 13
+        s = kw["SCENARIO"]
+        self.SCENARIO_NAME, self.FLIP_AXIS, self.GRID_SIZE = s["SCENARIO_NAME"], s["FLIP_AXIS"], s["GRID_SIZE"]
+        self.FLAG_POSITIONS, self.CAPTURE_POSITIONS = s["FLAG_POSITIONS"], s["CAPTURE_POSITIONS"]
+        self.SPAWN_POSITIONS, self.AGENT_STARTING_POSITIONS = s["SPAWN_POSITIONS"], s["AGENT_STARTING_POSITIONS"]
+        self.OPPONENTS = d["opponents"]
+        self.TILES_USED = d["tiles_used"]
+        self.agent_teams_np = np.array([v for v in self.AGENT_TEAMS.values()], dtype=np.uint8)
+        self.grid = np.zeros((self.GRID_SIZE, self.GRID_SIZE), dtype=np.uint8)  # live array, updated in place
+        self.has_flag = np.zeros(self.N_AGENTS, dtype=np.uint8)
+        self._obs_cache = None
+        self.reset()
+
+    # -- pickling / deepcopy (Ray hands the env to workers by value) ------------------------------
+    def __getstate__(self):
+        return dict(ctor=self._ctor, view=bytes(self._vec.get_state(0)), rng=self._vec.get_rng_state(0))
+
+    def __setstate__(self, state):
+        c = state["ctor"]
+        self.__init__(rng=c["rng"], seed=c["seed"], device=c["device"], **c["kwargs"])
+        view = _abi.CtfStateView.from_buffer_copy(state["view"])
+        self._vec.set_state(0, view)
+        self._vec.set_rng_state(0, *state["rng"])
+        self._pull()
+
+    def __deepcopy__(self, memo):
+        new = object.__new__(type(self))
+        new.__setstate__(self.__getstate__())
+        return new
+
+    # -- host mirror of the device state --------------------------------------------------------
+    def _pull(self):
+        v = self._vec.get_state(0)
+        n, g = self.N_AGENTS, self.GRID_SIZE
+        self.grid[...] = np.frombuffer(v.grid, dtype=np.uint8, count=g * g).reshape(g, g)
+        self.agent_positions = {i: (int(v.pos[i][0]), int(v.pos[i][1])) for i in range(n)}
+        self.has_flag[...] = np.frombuffer(v.has_flag, dtype=np.uint8, count=n)
+        self.agent_hp = {i: v.hp[i] for i in range(n)}
+        self.block_inventory = {i: int(v.inventory[i]) for i in range(n)}
+        self._arr = [int(v.perm[i]) for i in range(n)]
+        self.env_step_count = int(v.step_count)
+        self.done = bool(v.done)
+        self._view = v
+        self._obs_cache = None
+
+    @property
+    def metrics(self):
+        """The reference's metrics dict (gridworld_ctf.py:425-470), rebuilt from the device counters:
+        team_* and agent_type_* entries are sums of the agent-level counters, as in the reference."""
+        v, n, g = self._view, self.N_AGENTS, self.GRID_SIZE
+        out = {"team_wins": {0: 0, 1: 0}}
+        for k, name in enumerate(_abi.METRIC_NAMES):
+            team = {0: 0, 1: 0}
+            by_type = defaultdict(partial(defaultdict, int))
+            agent = defaultdict(int)
+            for i in range(n):
+                val = int(v.metrics[k][i])
+                if val:
+                    agent[i] = val
+                    team[self.AGENT_TEAMS[i]] += val
+                    by_type[self.AGENT_TEAMS[i]][self.AGENT_TYPES[i]] += val
+            out["team_" + name], out["agent_type_" + name], out["agent_" + name] = team, by_type, agent
+        out["team_flag_captures"] = {0: int(v.team_captures[0]), 1: int(v.team_captures[1])}
+        vis = defaultdict(partial(np.zeros, (g, g), dtype=np.uint8))
+        for i in range(n):
+            vis[i] = np.frombuffer(v.visitation[i], dtype=np.uint8, count=g * g).reshape(g, g).copy()
+        out["agent_visitation_maps"] = vis
+        return out
+
+    # -- reference API ----------------------------------------------------------------------------
+    def reset(self):
+        self._vec.reset()
+        self._pull()
+        if self.MAP_SYMMETRY_CHECK:
+            assert np.all(self.standardise_state(0) == self.standardise_state(1, reverse_grid=True))
+
+    def _push_global_rng(self):
+        py = np.array(_py_random.getstate()[1], dtype=np.uint32)
+        st = np.random.get_state()
+        npw = np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)])
+        self._vec.set_rng_state(0, py, npw)
+        return st
+
+    def _pull_global_rng(self, np_state_before):
+        py, npw = self._vec.get_rng_state(0)
+        _py_random.setstate((3, tuple(int(x) for x in py), None))
+        np.random.set_state((np_state_before[0], npw[:624].copy(), int(npw[624]), np_state_before[3], np_state_before[4]))
+
+    def step(self, actions):
+        torch = _torch()
+        acts = [actions[i] for i in range(self.N_AGENTS)]
+        for i, a in enumerate(acts):
+            if not (isinstance(a, (int, np.integer)) and 0 <= int(a) <= 8):
+                raise KeyError(a)  # ACTION_DELTAS[type][action] in the reference
+        st = self._push_global_rng() if self._rng_mode == "global" else None
+        dev = torch.tensor([[int(a) for a in acts]], dtype=torch.int8, device=self._vec.device)
+        self._vec.step(dev, want_f64=True)
+        rewards = [float(x) for x in self._vec.rewards64[0].cpu().numpy()]
+        status = self._vec.status()
+        if st is not None:
+            self._pull_global_rng(st)
+        self._pull()
+        if status & _abi.ST_NO_RESPAWN:
+            raise ValueError("high <= 0")  # np.random.randint(0) in the reference's respawn
+        if status & _abi.ST_SPAWN_EDGE:
+            raise IndexError("respawn window clipped at row/col 0: the reference misplaces the agent here")
+        return self.grid, rewards, self.done
+
+    def _observe(self, reverse_mask):
+        if self._obs_cache is None or self._obs_cache[0] != reverse_mask:
+            obs, meta = self._vec.observe(reverse_mask)
+            self._obs_cache = (reverse_mask, obs[0].cpu().numpy(), meta[0].cpu().numpy())
+        return self._obs_cache
+
+    def _default_reverse_mask(self):
+        return sum(1 << i for i in range(self.N_AGENTS) if self.AGENT_TEAMS[i] == 1)
+
+    def standardise_state(self, agent_idx, reverse_grid=False):
+        i = int(agent_idx)
+        mask = self._default_reverse_mask()
+        if bool(reverse_grid) != bool((mask >> i) & 1):
+            mask ^= 1 << i
+        return self._observe(mask)[1][i][None].copy()
+
+    def get_env_metadata(self, agent_idx):
+        for t in self.AGENT_TYPES.values():
+            if t not in self.agent_hp:
+                raise KeyError(t)  # the reference indexes agent_hp by type id (gridworld_ctf.py:1041)
+        mask = self._obs_cache[0] if self._obs_cache is not None else self._default_reverse_mask()
+        return self._observe(mask)[2][int(agent_idx)][None].copy()
+
+    def get_env_dims(self):
+        c, g, n = len(self.TILES_USED) + 1, self.GRID_SIZE, self.N_AGENTS
+        return (c, g, g), (c - 1, g, g), (n * 2 + 6,), (n * 6 + n * self.ACTION_SPACE + 3,)
+
+    def get_reversed_action(self, action):
+        return self.REVERSED_ACTION_MAP[self.FLIP_AXIS][action]
+
+    def get_tiles_used(self):
+        return list(self.TILES_USED)
+
+    def max_dim_distance_to_xy(self, xy, target_xy):
+        return max(abs(xy[0] - target_xy[0]), abs(xy[1] - target_xy[1]))
+
+    def agent_distance_to_xy(self, agent_idx, object_xy):
+        return self.max_dim_distance_to_xy(self.agent_positions[agent_idx], object_xy)
+
+    def render(self, sleep_time=0.2, ego_state_agent=None):
+        """Minimal matplotlib view of the grid (presentation is outside the accelerated path)."""
+        import matplotlib.pyplot as plt
+
+        plt.figure(num="env_render")
+        plt.clf()
+        plt.imshow(self.grid, vmin=0, vmax=13, cmap="tab20")
+        plt.title(f"step {self.env_step_count}")
+        plt.pause(sleep_time)

@@ -1,0 +1,53 @@
+/*
+ * ctf_oracle.h — CPU restatement of the reference GridworldCtf hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (marl-ctf-development_amd/) may include,
+ * link or call this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker / reported baseline.
+ *
+ * Parity status: PINNED — this restatement is checked bit-exactly against trajectories produced by
+ * importing the reference itself (tests/golden/make_golden.py writes the .npz fixtures in tests/golden) and
+ * against the reference's own known answers (env_testing.ipynb outputs, MAP_SYMMETRY_CHECK).
+ */
+#ifndef CTF_ORACLE_H
+#define CTF_ORACLE_H
+
+#include "../include/ctf_env.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct octf_env octf_env; /* ONE environment, host memory */
+
+octf_env* octf_create(const ctf_config* cfg);
+void octf_destroy(octf_env* e);
+
+/* random.seed(py_seed) / np.random.seed(np_seed) */
+void octf_seed(octf_env* e, uint64_t py_seed, uint64_t np_seed);
+void octf_set_rng_state(octf_env* e, const uint32_t* py_mt625, const uint32_t* np_mt625);
+void octf_get_rng_state(const octf_env* e, uint32_t* py_mt625, uint32_t* np_mt625);
+
+void octf_reset(octf_env* e);
+/* returns CTF_ST_* bits raised by this step */
+uint32_t octf_step(octf_env* e, const int8_t* actions, double* rewards, uint8_t* done);
+void octf_observe(const octf_env* e, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask);
+void octf_get_state(const octf_env* e, ctf_state_view* out);
+void octf_set_state(octf_env* e, const ctf_state_view* in);
+
+/* helpers shared with the tests */
+uint16_t octf_f64_to_f16(double d);
+void octf_philox_actions(int8_t* actions, int32_t n_agents, uint64_t seed, uint32_t step, uint32_t env_index);
+
+/*
+ * CPU baseline driver (bench.py cpu_baseline leg): runs `n_envs` independent envs for `n_steps`
+ * steps of step()+observe() with Philox actions on `n_threads` threads (OpenMP over envs).
+ * Returns a checksum of everything produced so the work cannot be optimised away.
+ */
+uint64_t octf_run_batch(const ctf_config* cfg, int32_t n_envs, int32_t n_steps, uint64_t seed_base,
+                        uint64_t action_seed, int32_t with_observe, int32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
