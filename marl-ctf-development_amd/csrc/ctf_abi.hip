@@ -1,0 +1,453 @@
+// ctf_abi.hip — host side of the C ABI declared in include/ctf_env.h.
+//
+// Owns the device-side SoA state of one handle (one per GPU / shard), validates the config, derives
+// the device constant block and enqueues the kernels of ctf_kernels.hip on the caller's HIP stream.
+// No torch, no C++ types across the boundary, no CPU implementation of the path.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ctf_device.h"
+
+extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint64_t*, const uint64_t*, hipStream_t);
+extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
+extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, hipStream_t);
+extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
+extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
+
+struct ctf_env {
+    ctf_config cfg;
+    DevCfg d;
+    DevPtrs p;
+    int device;
+    int n_cus;
+    uint64_t* seed_scratch;  // device, 2*E u64
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) return fail(CTF_E_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// remembers and restores the caller's current device
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+static int ceil_log2(uint32_t d) {
+    int l = 0;
+    while ((1u << l) < d) l++;
+    return l;
+}
+// Granlund-Montgomery round-up reciprocal, exact for every n < n_max (checked exhaustively)
+static bool make_fastdiv(uint32_t d, uint32_t n_max, FastDiv* out) {
+    int nbits = ceil_log2(n_max + 1);
+    if (nbits < 1) nbits = 1;
+    const int s = nbits + ceil_log2(d);
+    if (s > 62) return false;
+    const uint64_t m = ((1ull << s) + d - 1) / d;
+    if (m > 0xFFFFFFFFull) return false;
+    out->m = (uint32_t)m;
+    out->s = (uint32_t)s;
+    for (uint32_t n = 0; n < n_max; n++)
+        if ((uint32_t)(((uint64_t)n * out->m) >> out->s) != n / d) return false;
+    return true;
+}
+
+static int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
+    memset(d, 0, sizeof(*d));
+    if (c->abi_version != CTF_ABI_VERSION) return fail(CTF_E_INVALID, "ctf_config.abi_version %d != %d", c->abi_version, CTF_ABI_VERSION);
+    if (n_envs < 1) return fail(CTF_E_INVALID, "n_envs must be >= 1");
+    const int N = c->n_agents, G = c->grid_size, C = c->n_channels;
+    if (N < 2 || N > CTF_MAX_AGENTS) return fail(CTF_E_INVALID, "n_agents %d outside 2..%d", N, CTF_MAX_AGENTS);
+    if (G < 4 || G > CTF_MAX_GRID) return fail(CTF_E_INVALID, "grid_size %d outside 4..%d", G, CTF_MAX_GRID);
+    if (C < 2 || C > 15) return fail(CTF_E_INVALID, "n_channels %d outside 2..15", C);
+    if (c->game_steps < 1) return fail(CTF_E_INVALID, "game_steps must be >= 1");
+    if (c->flip_axis < -1 || c->flip_axis > 2) return fail(CTF_E_INVALID, "flip_axis %d", c->flip_axis);
+    for (int t = 0; t < 2; t++) {
+        if (c->n_opponents[t] < 0 || c->n_opponents[t] > N) return fail(CTF_E_INVALID, "n_opponents[%d]", t);
+        for (int k = 0; k < c->n_opponents[t]; k++)
+            if (c->opponents[t][k] < 0 || c->opponents[t][k] >= N) return fail(CTF_E_INVALID, "opponents[%d][%d]", t, k);
+        const int8_t* pos[3] = {c->flag_pos[t], c->capture_pos[t], c->spawn_pos[t]};
+        for (int k = 0; k < 3; k++)
+            if (pos[k][0] < 0 || pos[k][0] >= G || pos[k][1] < 0 || pos[k][1] >= G) return fail(CTF_E_INVALID, "team %d position outside the grid", t);
+    }
+    for (int i = 0; i < N; i++) {
+        if (c->agent_team[i] < 0 || c->agent_team[i] > 1) return fail(CTF_E_INVALID, "agent_team[%d]", i);
+        if (c->agent_type[i] < 0 || c->agent_type[i] > 3) return fail(CTF_E_INVALID, "agent_type[%d]", i);
+        if (c->start_pos[i][0] < 0 || c->start_pos[i][0] >= G || c->start_pos[i][1] < 0 || c->start_pos[i][1] >= G)
+            return fail(CTF_E_INVALID, "start_pos[%d] outside the grid", i);
+        if (!(c->type_hp[c->agent_type[i]] > 0)) return fail(CTF_E_INVALID, "type_hp of agent %d must be > 0", i);
+    }
+    for (int k = 1; k < C; k++)
+        if (c->tile_of_channel[k] < 1 || c->tile_of_channel[k] > 13) return fail(CTF_E_INVALID, "tile_of_channel[%d]", k);
+    for (int k = 0; k < G * G; k++)
+        if (c->init_grid[k] > 13) return fail(CTF_E_INVALID, "init_grid[%d] = %d", k, c->init_grid[k]);
+
+    d->n_envs = n_envs; d->N = N; d->G = G; d->GG = G * G; d->C = C; d->M = 2 * N + 6;
+    d->game_steps = c->game_steps; d->flip_axis = c->flip_axis;
+    d->home_flag_capture = c->home_flag_capture; d->use_adjusted = c->use_adjusted_rewards;
+    d->drop_flag = c->drop_flag_when_no_hp; d->log_metrics = c->log_metrics ? 1 : 0;
+    d->n_opp[0] = c->n_opponents[0]; d->n_opp[1] = c->n_opponents[1];
+    d->GS = round_up(G * G, 16);
+    d->off_pos = 8 * N; d->off_flag = 10 * N; d->off_perm = 11 * N; d->off_inv = 12 * N;
+    d->off_misc = round_up(14 * N, 4);
+    d->RS = round_up(d->off_misc + 16, 16);
+    d->CGG = C * G * G; d->obs_bytes = N * d->CGG;
+    if (!make_fastdiv((uint32_t)d->CGG, (uint32_t)d->obs_bytes + 16, &d->div_cgg) ||
+        !make_fastdiv((uint32_t)d->GG, (uint32_t)d->CGG + 16, &d->div_gg) ||
+        !make_fastdiv((uint32_t)G, (uint32_t)d->GS + 4, &d->div_g) ||
+        !make_fastdiv((uint32_t)d->M, (uint32_t)(N * d->M) + 64, &d->div_m))
+        return fail(CTF_E_INVALID, "internal: reciprocal division not exact for these dimensions");
+    d->heal = c->heal_per_step; d->tag_p = c->tag_probability; d->guard_mult = c->guardian_damage_multiplier;
+    d->vault_cost = c->vault_hp_cost; d->vault_min = c->vault_min_hp;
+    d->r_capture = c->reward_capture; d->r_step = c->reward_step; d->r_tag = c->reward_tag;
+    d->win_scalar = c->win_margin_scalar; d->loss_scalar = c->loss_margin_scalar; d->punish = c->opp_capture_punishment;
+    for (int t = 0; t < 4; t++) { d->type_hp[t] = c->type_hp[t]; d->type_damage[t] = c->type_damage[t]; }
+    memcpy(d->team, c->agent_team, sizeof(d->team));
+    memcpy(d->type, c->agent_type, sizeof(d->type));
+    memcpy(d->opp, c->opponents, sizeof(d->opp));
+    memcpy(d->flag_pos, c->flag_pos, sizeof(d->flag_pos));
+    memcpy(d->capture_pos, c->capture_pos, sizeof(d->capture_pos));
+    memcpy(d->spawn_pos, c->spawn_pos, sizeof(d->spawn_pos));
+    memcpy(d->start_pos, c->start_pos, sizeof(d->start_pos));
+    for (int i = 0; i < N; i++) d->default_reverse |= (c->agent_team[i] == 1) ? (1 << i) : 0;
+
+    // channel of every tile value as seen by a viewer of team t (reference gridworld_ctf.py:987-994: for a
+    // team-1 viewer own/opponent agent tiles 4..7 <-> 8..11 and the flags 12 <-> 13 swap), 15 = no plane
+    for (int t = 0; t < 2; t++) {
+        uint64_t lut = 0;
+        for (int v = 0; v < 16; v++) {
+            int std_tile = v;
+            if (t == 1) {
+                if (v >= 4 && v <= 7) std_tile = v + 4;
+                else if (v >= 8 && v <= 11) std_tile = v - 4;
+                else if (v == 12) std_tile = 13;
+                else if (v == 13) std_tile = 12;
+            }
+            uint64_t code = CTF_TILE_NONE;
+            if (v >= 1 && v <= 13)
+                for (int k = 1; k < C; k++)
+                    if (c->tile_of_channel[k] == std_tile) code = (uint64_t)k;
+            lut |= code << (4 * v);
+        }
+        d->chan_lut[t] = lut;
+    }
+    // metadata order (gridworld_ctf.py:1053-1067): own-team list minus self, then the opponents list
+    for (int i = 0; i < N; i++) {
+        int n = 0, team = c->agent_team[i];
+        for (int k = 0; k < CTF_MAX_AGENTS; k++) d->meta_order[i][k] = -1;
+        for (int k = 0; k < c->n_opponents[1 - team]; k++)
+            if (c->opponents[1 - team][k] != i && n < N - 1) d->meta_order[i][n++] = c->opponents[1 - team][k];
+        for (int k = 0; k < c->n_opponents[team]; k++)
+            if (n < N - 1) d->meta_order[i][n++] = c->opponents[team][k];
+    }
+    return CTF_OK;
+}
+
+static void free_all(ctf_env* h) {
+    if (!h) return;
+    (void)hipFree(h->p.grid); (void)hipFree(h->p.rec); (void)hipFree(h->p.mt_py); (void)hipFree(h->p.mt_np);
+    (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis);
+    (void)hipFree((void*)h->p.init_grid); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
+    delete h;
+}
+
+extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_id, ctf_env** out) {
+    if (!cfg || !out) return fail(CTF_E_INVALID, "null argument");
+    *out = nullptr;
+    DevCfg d;
+    int rc = derive(cfg, n_envs, &d);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(CTF_E_INVALID, "device %d of %d", device_id, ndev);
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(CTF_E_HIP, "hipSetDevice(%d) failed", device_id);
+    ctf_env* h = new (std::nothrow) ctf_env();
+    if (!h) return fail(CTF_E_NOMEM, "host allocation failed");
+    memset(&h->p, 0, sizeof(h->p));
+    h->seed_scratch = nullptr;
+    h->cfg = *cfg; h->d = d; h->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
+    h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const size_t E = (size_t)n_envs;
+    const size_t vis_elems = d.log_metrics ? E * d.N * d.GS : 1, met_elems = d.log_metrics ? E * CTF_N_METRICS * d.N : 1;
+#define ALLOC(ptr, bytes)                                                                                      \
+    if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { free_all(h); return fail(CTF_E_NOMEM, "hipMalloc(%zu) failed", (size_t)(bytes)); }
+    ALLOC(h->p.grid, E * d.GS);
+    ALLOC(h->p.rec, E * d.RS);
+    ALLOC(h->p.mt_py, E * CTF_MT_N * 4);
+    ALLOC(h->p.mt_np, E * CTF_MT_N * 4);
+    ALLOC(h->p.rngpos, E * 2 * 4);
+    ALLOC(h->p.metrics, met_elems * 4);
+    ALLOC(h->p.vis, vis_elems * 4);
+    ALLOC(h->p.init_grid, (size_t)d.GS);
+    ALLOC(h->p.status, 4);
+    ALLOC(h->seed_scratch, E * 2 * 8);
+#undef ALLOC
+    std::vector<uint8_t> g0((size_t)d.GS, 0);
+    memcpy(g0.data(), cfg->init_grid, (size_t)d.GG);
+    hipError_t e1 = hipMemcpy((void*)h->p.init_grid, g0.data(), (size_t)d.GS, hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemset(h->p.status, 0, 4);
+    hipError_t e3 = hipMemset(h->p.rec, 0, E * d.RS);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "device initialisation failed"); }
+    // first reset (+ _arr = [0..N-1], gridworld_ctf.py:244) and seeds 0/0
+    hipError_t e4 = ctf_launch_reset(h->d, h->p, nullptr, 1, nullptr);
+    hipError_t e5 = hipMemset(h->seed_scratch, 0, E * 2 * 8);
+    hipError_t e6 = ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, nullptr);
+    hipError_t e7 = hipDeviceSynchronize();
+    if (e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
+        const hipError_t bad = e4 != hipSuccess ? e4 : e5 != hipSuccess ? e5 : e6 != hipSuccess ? e6 : e7;
+        free_all(h);
+        return fail(CTF_E_HIP, "first reset/seed failed: %s", hipGetErrorString(bad));
+    }
+    *out = h;
+    return CTF_OK;
+}
+
+extern "C" void ctf_destroy(ctf_env* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    free_all(h);
+}
+
+extern "C" int32_t ctf_n_envs(const ctf_env* h) { return h ? h->d.n_envs : 0; }
+extern "C" int64_t ctf_obs_bytes_per_env(const ctf_env* h) { return h ? h->d.obs_bytes : 0; }
+extern "C" int64_t ctf_meta_elems_per_env(const ctf_env* h) { return h ? (int64_t)h->d.N * h->d.M : 0; }
+extern "C" const char* ctf_last_error(void) { return g_err; }
+extern "C" int32_t ctf_abi_version(void) { return CTF_ABI_VERSION; }
+extern "C" int32_t ctf_sizeof_config(void) { return (int32_t)sizeof(ctf_config); }
+extern "C" int32_t ctf_sizeof_state_view(void) { return (int32_t)sizeof(ctf_state_view); }
+
+extern "C" int ctf_seed(ctf_env* h, const uint64_t* py_seeds, const uint64_t* np_seeds, void* stream) {
+    if (!h || !py_seeds || !np_seeds) return fail(CTF_E_INVALID, "null argument");
+    DeviceGuard guard(h->device);
+    const size_t E = (size_t)h->d.n_envs;
+    for (size_t e = 0; e < E; e++)
+        if (np_seeds[e] >> 32) return fail(CTF_E_INVALID, "np seed %zu must be < 2**32 (np.random.seed's own limit)", e);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->seed_scratch, py_seeds, E * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->seed_scratch + E, np_seeds, E * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the host arrays are the caller's; do not outlive the call
+    return CTF_OK;
+}
+
+extern "C" int ctf_set_rng_state(ctf_env* h, int32_t e, const uint32_t* py, const uint32_t* np_) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    const uint32_t* src[2] = {py, np_};
+    uint32_t* dst[2] = {h->p.mt_py, h->p.mt_np};
+    for (int k = 0; k < 2; k++) {
+        if (!src[k]) continue;
+        if (src[k][CTF_MT_N] > CTF_MT_N) return fail(CTF_E_INVALID, "MT position %u > 624", src[k][CTF_MT_N]);
+        HIP_TRY(hipMemcpy(dst[k] + (size_t)e * CTF_MT_N, src[k], CTF_MT_N * 4, hipMemcpyHostToDevice));
+        const uint32_t packed = src[k][CTF_MT_N];  // lazy flag clear: words [pos,624) are output as they stand
+        HIP_TRY(hipMemcpy(h->p.rngpos + 2 * (size_t)e + k, &packed, 4, hipMemcpyHostToDevice));
+    }
+    return CTF_OK;
+}
+
+// Brings a lazily regenerated block into the standard form (all 624 words of the current block).
+static void finish_block(uint32_t* a, uint32_t pos) {
+    for (uint32_t i = pos; i < CTF_MT_N; i++) {
+        const uint32_t i1 = (i + 1 == CTF_MT_N) ? 0u : i + 1;
+        const uint32_t im = (i + 397 >= CTF_MT_N) ? i + 397 - CTF_MT_N : i + 397;
+        const uint32_t y = (a[i] & 0x80000000u) | (a[i1] & 0x7fffffffu);
+        a[i] = a[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+}
+
+extern "C" int ctf_get_rng_state(ctf_env* h, int32_t e, uint32_t* py, uint32_t* np_) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t* dst[2] = {py, np_};
+    const uint32_t* src[2] = {h->p.mt_py, h->p.mt_np};
+    for (int k = 0; k < 2; k++) {
+        if (!dst[k]) continue;
+        uint32_t packed = 0;
+        HIP_TRY(hipMemcpy(dst[k], src[k] + (size_t)e * CTF_MT_N, CTF_MT_N * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&packed, h->p.rngpos + 2 * (size_t)e + k, 4, hipMemcpyDeviceToHost));
+        const uint32_t pos = packed & CTF_POS_MASK;
+        if (packed & CTF_LAZY_BIT) finish_block(dst[k], pos);
+        dst[k][CTF_MT_N] = pos;
+    }
+    return CTF_OK;
+}
+
+extern "C" int ctf_reset(ctf_env* h, const uint8_t* mask_dev, void* stream) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_reset(h->d, h->p, mask_dev, 0, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+extern "C" int ctf_step(ctf_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags, void* stream) {
+    if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+static uint32_t resolve_reverse(const ctf_env* h, uint32_t reverse_mask) {
+    return reverse_mask == CTF_REVERSE_DEFAULT ? (uint32_t)h->d.default_reverse : (reverse_mask & ((1u << h->d.N) - 1u));
+}
+
+extern "C" int ctf_observe(ctf_env* h, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask, void* stream) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (!obs && !meta) return CTF_OK;
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint8_t* obs,
+                                uint16_t* meta, uint32_t reverse_mask, uint32_t flags, void* stream) {
+    if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, (hipStream_t)stream));
+    if (obs || meta)
+        HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+extern "C" int ctf_action_mask(const ctf_env* h, uint8_t* mask_host) {
+    if (!h || !mask_host) return fail(CTF_E_INVALID, "null argument");
+    static const int type_flag[4] = {1, 1, 0, 0};  // AGENT_TYPE_ACTION_MASK, gridworld_ctf.py:218-223
+    for (int i = 0; i < h->d.N; i++)
+        for (int a = 0; a < CTF_N_ACTIONS; a++) mask_host[i * CTF_N_ACTIONS + a] = (type_flag[h->d.type[i]] && a >= 5) ? 0 : 1;
+    return CTF_OK;
+}
+
+extern "C" int ctf_get_state(ctf_env* h, int32_t e, ctf_state_view* out) {
+    if (!h || !out) return fail(CTF_E_INVALID, "null argument");
+    if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
+    DeviceGuard guard(h->device);
+    const DevCfg& d = h->d;
+    HIP_TRY(hipDeviceSynchronize());
+    memset(out, 0, sizeof(*out));
+    std::vector<uint8_t> rec((size_t)d.RS), grid((size_t)d.GS);
+    HIP_TRY(hipMemcpy(grid.data(), h->p.grid + (size_t)e * d.GS, (size_t)d.GS, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rec.data(), h->p.rec + (size_t)e * d.RS, (size_t)d.RS, hipMemcpyDeviceToHost));
+    memcpy(out->grid, grid.data(), (size_t)d.GG);
+    for (int i = 0; i < d.N; i++) {
+        memcpy(&out->hp[i], rec.data() + 8 * i, 8);
+        out->pos[i][0] = (int8_t)rec[d.off_pos + 2 * i];
+        out->pos[i][1] = (int8_t)rec[d.off_pos + 2 * i + 1];
+        out->has_flag[i] = rec[d.off_flag + i];
+        out->perm[i] = rec[d.off_perm + i];
+        int16_t inv;
+        memcpy(&inv, rec.data() + d.off_inv + 2 * i, 2);
+        out->inventory[i] = inv;
+    }
+    int32_t misc[4];
+    memcpy(misc, rec.data() + d.off_misc, 16);
+    out->step_count = misc[0];
+    out->team_captures[0] = misc[1];
+    out->team_captures[1] = misc[2];
+    out->done = misc[3];
+    if (d.log_metrics) {
+        std::vector<int32_t> m((size_t)CTF_N_METRICS * d.N);
+        HIP_TRY(hipMemcpy(m.data(), h->p.metrics + (size_t)e * CTF_N_METRICS * d.N, m.size() * 4, hipMemcpyDeviceToHost));
+        for (int k = 0; k < CTF_N_METRICS; k++)
+            for (int i = 0; i < d.N; i++) out->metrics[k][i] = m[(size_t)k * d.N + i];
+        std::vector<uint32_t> v((size_t)d.N * d.GS);
+        HIP_TRY(hipMemcpy(v.data(), h->p.vis + (size_t)e * d.N * d.GS, v.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < d.N; i++)
+            for (int k = 0; k < d.GG; k++) out->visitation[i][k] = (uint8_t)(v[(size_t)i * d.GS + k] & 0xFFu);  // u8 wraps in the reference
+    }
+    return CTF_OK;
+}
+
+extern "C" int ctf_set_state(ctf_env* h, int32_t e, const ctf_state_view* in) {
+    if (!h || !in) return fail(CTF_E_INVALID, "null argument");
+    if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
+    DeviceGuard guard(h->device);
+    const DevCfg& d = h->d;
+    for (int i = 0; i < d.N; i++) {
+        if (in->pos[i][0] < 0 || in->pos[i][0] >= d.G || in->pos[i][1] < 0 || in->pos[i][1] >= d.G)
+            return fail(CTF_E_INVALID, "pos[%d] outside the grid", i);
+        if (in->perm[i] >= d.N) return fail(CTF_E_INVALID, "perm[%d]", i);
+        if (in->inventory[i] < 0 || in->inventory[i] > 1000) return fail(CTF_E_INVALID, "inventory[%d]", i);
+    }
+    for (int k = 0; k < d.GG; k++)
+        if (in->grid[k] > 13) return fail(CTF_E_INVALID, "grid[%d]", k);
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint8_t> rec((size_t)d.RS, 0), grid((size_t)d.GS, 0);
+    memcpy(grid.data(), in->grid, (size_t)d.GG);
+    for (int i = 0; i < d.N; i++) {
+        memcpy(rec.data() + 8 * i, &in->hp[i], 8);
+        rec[d.off_pos + 2 * i] = (uint8_t)in->pos[i][0];
+        rec[d.off_pos + 2 * i + 1] = (uint8_t)in->pos[i][1];
+        rec[d.off_flag + i] = in->has_flag[i];
+        rec[d.off_perm + i] = in->perm[i];
+        const int16_t inv = (int16_t)in->inventory[i];
+        memcpy(rec.data() + d.off_inv + 2 * i, &inv, 2);
+    }
+    const int32_t misc[4] = {in->step_count, in->team_captures[0], in->team_captures[1], in->done ? 1 : 0};
+    memcpy(rec.data() + d.off_misc, misc, 16);
+    HIP_TRY(hipMemcpy(h->p.grid + (size_t)e * d.GS, grid.data(), (size_t)d.GS, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->p.rec + (size_t)e * d.RS, rec.data(), (size_t)d.RS, hipMemcpyHostToDevice));
+    if (d.log_metrics) {
+        std::vector<int32_t> m((size_t)CTF_N_METRICS * d.N);
+        for (int k = 0; k < CTF_N_METRICS; k++)
+            for (int i = 0; i < d.N; i++) m[(size_t)k * d.N + i] = in->metrics[k][i];
+        HIP_TRY(hipMemcpy(h->p.metrics + (size_t)e * CTF_N_METRICS * d.N, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+        std::vector<uint32_t> v((size_t)d.N * d.GS, 0);
+        for (int i = 0; i < d.N; i++)
+            for (int k = 0; k < d.GG; k++) v[(size_t)i * d.GS + k] = in->visitation[i][k];
+        HIP_TRY(hipMemcpy(h->p.vis + (size_t)e * d.N * d.GS, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    }
+    return CTF_OK;
+}
+
+extern "C" int ctf_status(ctf_env* h, uint32_t* out_bits, void* stream) {
+    if (!h || !out_bits) return fail(CTF_E_INVALID, "null argument");
+    DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(out_bits, h->p.status, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(h->p.status, 0, 4, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CTF_OK;
+}
+
+extern "C" int ctf_random_actions(ctf_env* h, int8_t* actions, uint64_t seed, uint32_t step, uint32_t env_offset, void* stream) {
+    if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_random_actions(h->d, actions, seed, step, env_offset, (hipStream_t)stream));
+    return CTF_OK;
+}

@@ -1,0 +1,60 @@
+// ctf_device.h — device-side description of one GridworldCtf configuration and the HBM layout of the
+// per-env state.  Shared by the kernels (ctf_kernels.hip) and the C-ABI host code (ctf_abi.hip).
+//
+// HBM layout (E = n_envs), everything per-env-contiguous so that one wave moves one env's (or 64
+// envs') bytes with full-width coalesced accesses:
+//   grid   u8  [E][GS]        GS = G*G rounded up to 16; row-major tile codes (reference self.grid)
+//   rec    u8  [E][RS]        one record per env, RS multiple of 16:
+//                               f64 hp[N] | i8 pos[N][2] | u8 has_flag[N] | u8 perm[N] | i16 inv[N]
+//                               | i32 step | i32 caps[2] | u8 done | pad
+//   mt_py  u32 [E][624]       CPython `random` stream   (MT19937, lazily regenerated in place)
+//   mt_np  u32 [E][624]       NumPy legacy `np.random` stream
+//   rngpos u32 [E][2]         per stream: position (0..624) | lazy-flag << 16
+//   metric i32 [E][13][N]     agent-level counters (only when log_metrics)
+//   vis    u32 [E][N][GS]     visitation counters  (only when log_metrics; exported modulo 256)
+#pragma once
+#include <stdint.h>
+
+#include "../../include/ctf_env.h"
+
+#define CTF_TILE_NONE 15u  // channel code of a tile that has no observation plane
+
+struct FastDiv {  // q = (n * m) >> s, exact for every n the kernels use (verified on the host at create)
+    uint32_t m, s;
+};
+
+struct DevCfg {
+    int32_t n_envs, N, G, GG, C, M;
+    int32_t game_steps, flip_axis;
+    int32_t home_flag_capture, use_adjusted, drop_flag, log_metrics;
+    int32_t n_opp[2];
+    int32_t GS, RS;                 // strides of grid / rec in bytes
+    int32_t CGG, obs_bytes;         // C*G*G, N*C*G*G
+    int32_t off_pos, off_flag, off_perm, off_inv, off_misc;  // record offsets (hp is at 0)
+    int32_t default_reverse;        // bit i = (team(i) == 1)
+    FastDiv div_cgg, div_gg, div_g, div_m;
+    double heal, tag_p, guard_mult, vault_cost, vault_min;
+    double r_capture, r_step, r_tag, win_scalar, loss_scalar, punish;
+    double type_hp[4], type_damage[4];
+    uint64_t chan_lut[2];           // [viewer team]: nibble v = channel of tile v after relabelling, 15 = none
+    int8_t team[CTF_MAX_AGENTS], type[CTF_MAX_AGENTS];
+    int8_t opp[2][CTF_MAX_AGENTS];
+    int8_t flag_pos[2][2], capture_pos[2][2], spawn_pos[2][2];
+    int8_t start_pos[CTF_MAX_AGENTS][2];
+    int8_t meta_order[CTF_MAX_AGENTS][CTF_MAX_AGENTS];  // viewer i: teammates (ascending, not i) then opponents; -1 = none
+};
+
+struct DevPtrs {
+    uint8_t* grid;
+    uint8_t* rec;
+    uint32_t* mt_py;
+    uint32_t* mt_np;
+    uint32_t* rngpos;
+    int32_t* metrics;
+    uint32_t* vis;             // u32 counters [E][N][GS]; the reference's u8 maps are these modulo 256
+    const uint8_t* init_grid;  // GS bytes
+    uint32_t* status;
+};
+
+#define CTF_POS_MASK 0xFFFFu
+#define CTF_LAZY_BIT 0x10000u

@@ -147,6 +147,10 @@ def cases(scn):
     # the single open spawn cell may be occupied when the next team-1 agent dies (the reference then raises
     # ValueError, covered by its own test): search for a seed whose 250 steps never hit that
     out.append(dict(name="syn_edge_k1", scenario=SYN_EDGE, kwargs=edge, seed=41, aseed=42, T=250, p_high=0.1, seed_search=True))
+    # 1v1: the observation block (2*7*121 = 1694 bytes) is only 2-byte aligned from env to env
+    duo = dict(AGENT_CONFIG={0: {"team": 0, "type": 0}, 1: {"team": 1, "type": 1}}, GAME_STEPS=100, MAP_SYMMETRY_CHECK=False,
+               TAG_PROBABILITY=0.9)
+    out.append(dict(name="donut_1v1", scenario="donut", kwargs=duo, seed=61, aseed=62, T=130))
     a20 = dict(ARENA_KW, GRID_SIZE=20, GAME_STEPS=300)
     out.append(dict(name="syn_arena20", scenario=SYN_ARENA20, kwargs=a20, seed=51, aseed=52, T=300))
     # every shipped experiment script's env_config, unchanged (0_the_split.py ... 8_arena.py)

@@ -1,0 +1,299 @@
+"""Parity of the HIP path (through the C ABI) on a real MI355X: bit-exact against the golden vectors
+recorded from the reference and against the CPU oracle on seeded synthetic action streams."""
+import copy
+import importlib
+import pickle
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from _cases import Case, abi, case_names, pkg, view_arrays
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return 0
+
+
+def _state_equal(a, b, ctx):
+    for k in ("grid", "pos", "hp", "has_flag", "inv", "perm", "metrics", "visitation"):
+        assert np.array_equal(a[k], b[k]), f"{ctx}: {k}"
+    for k in ("step_count", "done", "team_captures"):
+        assert a[k] == b[k], f"{ctx}: {k}"
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_golden_trajectory(name):
+    """Env 0 of a 3-env batch replays the reference trajectory; envs 1,2 run other seeds beside it."""
+    case = Case(name)
+    z, n, g = case.z, case.n, case.g
+    seed = case.meta["seed"]
+    vec = pkg.VecGridworldCtf(3, device=_dev(), py_seeds=[seed, seed + 1, 0], np_seeds=[seed, seed + 1, 0], **case.kwargs)
+    assert vec.TILES_USED == case.meta["tiles_used"]
+    py0, np0 = case.seeded_states()
+    got_py, got_np = vec.get_rng_state(0)
+    assert np.array_equal(got_py, py0) and np.array_equal(got_np, np0), "device seeding != random.seed / np.random.seed"
+
+    obs, meta = vec.observe()
+    assert np.array_equal(obs[0].cpu().numpy(), case.unpack_obs(z["obs0"]))
+    assert np.array_equal(meta[0].cpu().numpy().view(np.uint16), z["meta0"])
+
+    extra = {int(t): k for k, t in enumerate(z["extra_steps"])}
+    acts = torch.zeros((3, n), dtype=torch.int8, device=vec.device)
+    mask0 = torch.tensor([1, 0, 0], dtype=torch.uint8, device=vec.device)
+    for t in range(case.T):
+        if t in case.reset_at:
+            vec.reset(mask0)
+        a = torch.from_numpy(z["actions"][t])
+        acts[0] = a
+        acts[1] = a
+        acts[2] = torch.from_numpy(z["actions"][(t * 7 + 3) % case.T])
+        _, done = vec.step(acts, want_f64=True)
+        obs, meta = vec.observe()
+        ctx = f"{name} step {t}"
+        assert np.array_equal(vec.rewards64[0].cpu().numpy(), z["rewards"][t]), ctx
+        assert np.array_equal(vec.rewards[0].cpu().numpy(), z["rewards"][t].astype(np.float32)), ctx
+        assert int(done[0]) == int(z["done"][t]), ctx
+        assert np.array_equal(obs[0].cpu().numpy(), case.unpack_obs(z["obs"][t])), ctx
+        assert np.array_equal(meta[0].cpu().numpy().view(np.uint16), z["meta"][t]), ctx
+        if t % 9 == 0 or t in extra or t >= case.T - 3:
+            s = view_arrays(vec.get_state(0), n, g)
+            assert np.array_equal(s["grid"], z["grid"][t]), ctx
+            assert np.array_equal(s["pos"], z["pos"][t]), ctx
+            assert np.array_equal(s["hp"], z["hp"][t]), ctx
+            assert np.array_equal(s["has_flag"], z["has_flag"][t]), ctx
+            assert np.array_equal(s["inv"], z["inv"][t]), ctx
+            assert np.array_equal(s["perm"], z["perm"][t]), ctx
+            py, npw = vec.get_rng_state(0)
+            assert (int(py[624]), int(npw[624])) == (int(z["py_pos"][t]), int(z["np_pos"][t])), ctx + " (draw counts)"
+        if t in extra:
+            o_unrev = vec.observe(reverse_mask=0)[0][0].cpu().numpy()
+            assert np.array_equal(o_unrev, case.unpack_obs(z["extra_obs_unrev"][extra[t]])), ctx
+            o_rev = vec.observe(reverse_mask=(1 << n) - 1)[0][0].cpu().numpy()
+            assert np.array_equal(o_rev, case.unpack_obs(z["extra_obs_rev"][extra[t]])), ctx
+
+    s = view_arrays(vec.get_state(0), n, g)
+    assert np.array_equal(s["metrics"], z["metrics"])
+    assert np.array_equal(s["visitation"], z["visitation"])
+    assert s["team_captures"] == case.meta["team_captures"]
+    py, npw = vec.get_rng_state(0)
+    assert np.array_equal(py, z["py_state"]) and np.array_equal(npw, z["np_state"])
+    assert vec.status() == 0
+    vec.close()
+
+
+@pytest.mark.parametrize("name,n_envs,steps,log_metrics", [
+    ("arena_random", 200, 160, True),     # partial last wave (200 = 3*64 + 8)
+    ("split_random", 4096, 64, True),     # BASELINE configs[1] size
+    ("arena_stress", 130, 320, False),    # metrics compiled out, auto-reset crossing the episode end
+    ("syn_axis1_drop", 96, 200, True),
+    ("fence_axis0", 70, 120, True),       # obs block not a multiple of 16 bytes (4-byte aligned stores)
+    ("syn_edge_k1", 64, 150, True),
+    ("donut_1v1", 77, 110, True),         # obs block only 2-byte aligned (byte-store path)
+])
+def test_batch_matches_oracle(name, n_envs, steps, log_metrics):
+    case = Case(name)
+    auto_reset = name == "arena_stress"
+    seeds = np.arange(n_envs, dtype=np.uint64) * 977 + 5
+    vec = pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=log_metrics, **case.kwargs)
+    cfg, _ = case.config(log_metrics=log_metrics)
+    refs = [oracle.OracleEnv(cfg) for _ in range(n_envs)]
+    for e, r in enumerate(refs):
+        r.seed(int(seeds[e]), int(seeds[e]))
+    acts = torch.empty((n_envs, case.n), dtype=torch.int8, device=vec.device)
+    alive = np.ones(n_envs, bool)  # envs whose oracle hit an error state (e.g. no respawn cell) are dropped
+    for t in range(steps):
+        vec.random_actions(acts, seed=0xC0FFEE, step=t, env_offset=11)
+        rewards, done, obs, meta = vec.step_observe(acts, auto_reset=auto_reset, want_f64=True)
+        a = acts.cpu().numpy()
+        r64 = vec.rewards64.cpu().numpy()
+        d = done.cpu().numpy()
+        o = obs.cpu().numpy()
+        m = meta.cpu().numpy().view(np.uint16)
+        for e, r in enumerate(refs):
+            if not alive[e]:
+                continue
+            assert np.array_equal(a[e], oracle.philox_actions(case.n, 0xC0FFEE, t, 11 + e))
+            if auto_reset and r.get_state().done:
+                r.reset()
+            rw, dn, status = r.step(a[e])
+            if status:
+                alive[e] = False
+                continue
+            ro, rm = r.observe()
+            ctx = f"{name} env {e} step {t}"
+            assert np.array_equal(r64[e], rw), ctx
+            assert int(d[e]) == int(dn), ctx
+            assert np.array_equal(o[e], ro), ctx
+            assert np.array_equal(m[e], rm.view(np.uint16)), ctx
+    assert alive.sum() >= n_envs // 2
+    for e in range(0, n_envs, max(1, n_envs // 16)):
+        if alive[e]:
+            _state_equal(view_arrays(vec.get_state(e), case.n, case.g), view_arrays(refs[e].get_state(), case.n, case.g), f"{name} env {e} final")
+            py, npw = vec.get_rng_state(e)
+            rpy, rnp = refs[e].get_rng_state()
+            assert np.array_equal(py, rpy) and np.array_equal(npw, rnp)
+    vec.close()
+
+
+def test_full_size_arena_properties_and_sample():
+    """BASELINE configs[2] size (65 536 arena envs): size-independent properties on everything plus a
+    bit-exact oracle check on a 64-env sample."""
+    case = Case("arena_random")
+    E, steps = 65536, 12
+    seeds = np.arange(E, dtype=np.uint64) + 1_000_003
+    vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=False, **case.kwargs)
+    cfg, _ = case.config(log_metrics=False)
+    sample = np.linspace(0, E - 1, 64).astype(int)
+    refs = {int(e): oracle.OracleEnv(cfg) for e in sample}
+    for e, r in refs.items():
+        r.seed(int(seeds[e]), int(seeds[e]))
+    acts = torch.empty((E, case.n), dtype=torch.int8, device=vec.device)
+    for t in range(steps):
+        vec.random_actions(acts, seed=7, step=t)
+        rewards, done, obs, meta = vec.step_observe(acts, want_f64=True)
+        # plane 0 of every agent is one-hot; every cell is hot in at most 2 planes (own position + a tile plane)
+        assert bool((obs[:, :, 0].sum(dim=(2, 3), dtype=torch.int32) == 1).all())
+        assert int(obs.max()) == 1
+        # team 0 sees exactly 4 own-team agent cells and 4 opponents (channels of tiles 4..7 / 8..11)
+        tiles = vec.TILES_USED
+        own = [k + 1 for k, tl in enumerate(tiles) if 4 <= tl <= 7]
+        opp = [k + 1 for k, tl in enumerate(tiles) if 8 <= tl <= 11]
+        assert bool((obs[:, :, own].sum(dim=(2, 3, 4), dtype=torch.int32) == 4).all())
+        assert bool((obs[:, :, opp].sum(dim=(2, 3, 4), dtype=torch.int32) == 4).all())
+        # a team-1 agent's reversed view of the walls equals a team-0 agent's view rotated by 180 degrees
+        wall = tiles.index(1) + 1
+        assert bool((obs[:, 0, wall] == torch.flip(obs[:, 1, wall], dims=(1, 2))).all())
+        a = acts[torch.from_numpy(sample).to(vec.device)].cpu().numpy()
+        o = obs[torch.from_numpy(sample).to(vec.device)].cpu().numpy()
+        m = meta[torch.from_numpy(sample).to(vec.device)].cpu().numpy().view(np.uint16)
+        r64 = vec.rewards64[torch.from_numpy(sample).to(vec.device)].cpu().numpy()
+        for k, e in enumerate(sample):
+            rw, dn, _ = refs[int(e)].step(a[k])
+            ro, rm = refs[int(e)].observe()
+            assert np.array_equal(r64[k], rw) and np.array_equal(o[k], ro) and np.array_equal(m[k], rm.view(np.uint16)), (t, e)
+    assert vec.status() == 0
+    vec.close()
+
+
+def test_reset_mask_and_state_roundtrip():
+    case = Case("arena_random")
+    vec = pkg.VecGridworldCtf(8, device=_dev(), **case.kwargs)
+    acts = torch.empty((8, case.n), dtype=torch.int8, device=vec.device)
+    for t in range(30):
+        vec.random_actions(acts, seed=3, step=t)
+        vec.step(acts)
+    before = [view_arrays(vec.get_state(e), case.n, case.g) for e in range(8)]
+    mask = torch.tensor([0, 1, 0, 0, 1, 0, 0, 0], dtype=torch.uint8, device=vec.device)
+    vec.reset(mask)
+    fresh = view_arrays(pkg.VecGridworldCtf(1, device=_dev(), **case.kwargs).get_state(0), case.n, case.g)
+    for e in range(8):
+        now = view_arrays(vec.get_state(e), case.n, case.g)
+        if mask[e]:
+            for k in ("grid", "pos", "hp", "has_flag", "inv", "metrics", "visitation"):
+                assert np.array_equal(now[k], fresh[k]), k
+            assert now["step_count"] == 0 and now["done"] == 0
+            assert np.array_equal(now["perm"], before[e]["perm"])  # _arr survives reset (gridworld_ctf.py:244)
+        else:
+            _state_equal(now, before[e], f"env {e} untouched")
+    # set_state(get_state) is the identity, also across envs
+    v = vec.get_state(3)
+    vec.set_state(5, v)
+    _state_equal(view_arrays(vec.get_state(5), case.n, case.g), view_arrays(v, case.n, case.g), "roundtrip")
+    py, npw = vec.get_rng_state(3)
+    vec.set_rng_state(5, py, npw)
+    vec.random_actions(acts, seed=9, step=0)
+    acts[5] = acts[3]
+    vec.step(acts, want_f64=True)
+    _state_equal(view_arrays(vec.get_state(5), case.n, case.g), view_arrays(vec.get_state(3), case.n, case.g), "twin envs")
+    assert np.array_equal(vec.rewards64[5].cpu().numpy(), vec.rewards64[3].cpu().numpy())
+    vec.close()
+
+
+def test_status_bits_for_bad_action_and_action_mask():
+    case = Case("split_random")
+    vec = pkg.VecGridworldCtf(4, device=_dev(), **case.kwargs)
+    acts = torch.zeros((4, case.n), dtype=torch.int8, device=vec.device)
+    acts[2, 1] = 9
+    vec.step(acts)
+    assert vec.status() & abi.ST_BAD_ACTION
+    assert vec.status() == 0  # cleared by the read
+    mask = vec.action_mask()
+    want = np.array([[1] * 5 + ([0] * 4 if vec.AGENT_TYPES[i] in (0, 1) else [1] * 4) for i in range(case.n)], np.uint8)
+    assert np.array_equal(mask, want)
+    vec.close()
+
+
+def test_facade_is_a_drop_in_for_the_reference_api():
+    """The single-env facade driven exactly as ppo.py / utils.duel drive the reference, global RNG contract included."""
+    case = Case("script_8_arena")
+    z, n = case.z, case.n
+    random.seed(case.meta["seed"])
+    np.random.seed(case.meta["seed"])
+    env = pkg.GridworldCtf(**case.kwargs)
+    assert env.get_env_dims()[0] == tuple(case.obs_shape[1:]) and env.get_env_dims()[2] == (case.meta["meta_len"],)
+    assert env.N_AGENTS == n and env.GRID_SIZE == case.g
+    for t in range(60):
+        for i in np.arange(env.N_AGENTS):  # np.int64 indices, as the reference's loops use
+            rev = env.AGENT_TEAMS[i] != 0
+            s = env.standardise_state(i, reverse_grid=rev)
+            m = env.get_env_metadata(i)
+            want_s = case.unpack_obs(z["obs"][t - 1] if t else z["obs0"])[i][None]
+            want_m = (z["meta"][t - 1] if t else z["meta0"])[i][None]
+            assert s.shape == want_s.shape and s.dtype == np.uint8 and np.array_equal(s, want_s)
+            assert m.dtype == np.float16 and np.array_equal(m.view(np.uint16), want_m)
+            assert env.AGENT_TYPE_ACTION_MASK[env.AGENT_TYPES[i]] in (0, 1)
+        grid, rewards, done = env.step([int(a) for a in z["actions"][t]])
+        assert grid is env.grid and np.array_equal(grid, z["grid"][t])
+        assert isinstance(rewards, list) and rewards == [float(r) for r in z["rewards"][t]]
+        assert done == bool(z["done"][t])
+        assert env.agent_positions == {i: tuple(int(x) for x in z["pos"][t][i]) for i in range(n)}
+        assert np.array_equal(env.has_flag, z["has_flag"][t])
+        assert env._arr == [int(x) for x in z["perm"][t]]
+        assert random.getstate()[1][624] == int(z["py_pos"][t]) and np.random.get_state()[2] == int(z["np_pos"][t])
+    assert env.get_reversed_action(0) == 1 and env.get_reversed_action(7) == 8  # FLIP_AXIS None
+    with pytest.raises(KeyError):
+        env.step([9] * n)
+    # travels by value like the reference env does under Ray (deepcopy / pickle), continuing identically
+    twin = copy.deepcopy(env)
+    blob = pickle.loads(pickle.dumps(env))
+    st_py, st_np = random.getstate(), np.random.get_state()
+    out_a = env.step([int(a) for a in z["actions"][60]])
+    for other in (twin, blob):
+        random.setstate(st_py)
+        np.random.set_state(st_np)
+        out_b = other.step([int(a) for a in z["actions"][60]])
+        assert np.array_equal(out_a[0], out_b[0]) and out_a[1] == out_b[1] and out_a[2] == out_b[2]
+    assert np.array_equal(out_a[0], z["grid"][60])
+    met = env.metrics
+    assert met["team_flag_captures"] == {0: 0, 1: 0} and set(met["agent_visitation_maps"]) == set(range(n))
+
+
+def test_symmetry_assertion_and_no_respawn_cell_errors_match_the_reference():
+    maps = pkg.CtfScenarios
+    bad = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=maps.arrow, MAP_SYMMETRY_CHECK=True)  # asymmetric types -> AssertionError
+    with pytest.raises(AssertionError):
+        pkg.GridworldCtf(**bad)
+    # a spawn whose 3x3 window has no open cell: np.random.randint(0) -> ValueError in the reference
+    scen = copy.deepcopy(maps.arrow)
+    scen["SPAWN_POSITIONS"] = {0: (6, 1), 1: (9, 9)}
+    scen["BLOCK_TILE_SLICES"] = list(scen["BLOCK_TILE_SLICES"]) + [(8, 8), (8, 9), (8, 10), (9, 8), (9, 10), (10, 8), (10, 9), (10, 10)]
+    scen["AGENT_STARTING_POSITIONS"] = {0: (5, 2), 1: (5, 3), 2: (5, 1), 3: (9, 5)}
+    kw = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=scen, TAG_PROBABILITY=1.0, AGENT_TYPE_HP={0: 1, 1: 8, 2: 8, 3: 7})
+    env = pkg.GridworldCtf(rng="device", seed=1, **kw)
+    with pytest.raises(ValueError):
+        for _ in range(20):
+            env.step([4, 4, 4, 4])  # agent 0 (guardian, team 0) stands next to agent 1 (team 1, hp 1)
+
+
+def test_one_hip_runtime_in_the_process():
+    maps_txt = open("/proc/self/maps").read()
+    libs = {line.split()[-1] for line in maps_txt.splitlines() if "libamdhip64" in line}
+    assert len(libs) == 1, libs
+    assert any("libctf_hip.so" in line for line in maps_txt.splitlines())

@@ -1,0 +1,64 @@
+"""Host-side logic of the boundary (no GPU): scenario painting, TILES_USED, OPPONENTS, config mapping."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from _cases import Case, case_names, cfgmod, maps, GOLDEN
+
+golden_maps = np.load(os.path.join(GOLDEN, "maps_ref.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(golden_maps.files))
+def test_shipped_maps_equal_the_reference_painting(name):
+    scen = getattr(maps, name)
+    g = scen["GRID_SIZE"]
+    grid = np.zeros((g, g), np.uint8)
+    for slc in scen["BLOCK_TILE_SLICES"]:
+        grid[slc] = 1
+    for slc in scen["DESTRUCTIBLE_TILE_SLICES"]:
+        grid[slc] = 2
+    assert np.array_equal(grid, golden_maps[name])
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_config_matches_reference_dims(name):
+    case = Case(name)
+    cfg, d = case.config()
+    assert d["tiles_used"] == case.meta["tiles_used"]  # channel order == the reference's TILES_USED
+    assert (cfg.n_agents, cfg.n_channels, cfg.grid_size, cfg.grid_size) == case.obs_shape
+    assert 2 * cfg.n_agents + 6 == case.meta["meta_len"]
+    assert (None if cfg.flip_axis == -1 else cfg.flip_axis) == case.meta["flip_axis"]
+    # the painted grid is the reference's grid before the first step, minus what step 0 changed: check via obs0
+    obs0 = case.unpack_obs(case.z["obs0"])
+    grid = np.array(cfg.init_grid[: case.g * case.g], np.uint8).reshape(case.g, case.g)
+    for k, tile in enumerate(d["tiles_used"]):
+        if tile in (1, 2, 3, 12, 13):  # team-independent tiles, agent 0 (team 0, not reversed)
+            assert np.array_equal(obs0[0, k + 1], (grid == tile).astype(np.uint8))
+
+
+def test_opponents_are_truncated_to_half():
+    teams = {0: 0, 1: 0, 2: 0, 3: 1}
+    opp = cfgmod.opponents_of(teams)
+    assert opp == {0: [3], 1: [0, 1]}
+
+
+def test_scenario_none_is_dead_like_the_reference():
+    with pytest.raises(AttributeError):
+        cfgmod.build_config({})
+
+
+def test_unknown_kwarg_raises_typeerror():
+    with pytest.raises(TypeError):
+        cfgmod.build_config({"SCENARIO": maps.arrow, "NOT_A_KWARG": 1})
+
+
+def test_reference_dims_known_answer():
+    # env_testing.ipynb cell 8 prints ((8, 11, 11), (7, 11, 11), (14,), (59,)) for a 2v2 arrow env whose
+    # agent 0 is a miner (cell 9's metadata has its type bit at index 5); that config gives 7 tiles here too
+    kw = {"SCENARIO": maps.arrow, "AGENT_CONFIG": {0: {"team": 0, "type": 3}, 1: {"team": 1, "type": 0},
+                                                   2: {"team": 0, "type": 0}, 3: {"team": 1, "type": 0}}}
+    cfg, d = cfgmod.build_config(kw)
+    n, c, g = cfg.n_agents, cfg.n_channels, cfg.grid_size
+    assert ((c, g, g), (c - 1, g, g), (2 * n + 6,), (6 * n + 8 * n + 3,)) == ((8, 11, 11), (7, 11, 11), (14,), (59,))
