@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched GridworldCtf hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: GridworldCtf.step() for every env of the shard
+plus the N observations + metadata rows a rollout consumes (reference ppo.py:59-98), with auto-reset at
+episode end.  Workload at N=1: BASELINE.json configs[2] — 8_arena (arena_iii, 4v4, the reference's
+15x15 map), 65 536 envs resident in HBM; N>1 keeps 65 536 envs per GPU (weak scaling), envs sharded by
+global index with no data-path collective, and the compact rollout tensors (rewards, done) all-gathered
+over RCCL each step, overlapped with the observation render.  Inputs (Philox action streams for every
+timed step) are generated on the device before the timed region.
+
+Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for the roofline / cpu_baseline fields).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def observe_algorithmic_bytes(n, c, g):
+    """Bytes one env MUST move in the observe launch: obs u8 [N][C][G][G] + metadata f16 [N][2N+6] written,
+    grid G*G + agent state (hp 8, pos 2, flag 1 per agent) + step/captures/done (13) read."""
+    return n * c * g * g + n * (2 * n + 6) * 2 + g * g + 11 * n + 13
+
+
+def step_algorithmic_bytes(n, g):
+    """SURVEY §8d terms of the step launch: grid r+w, agent state r+w (14 B/agent), actions in, f32 rewards +
+    done out, RNG words r+w (~N^2 + 2(N-1) words)."""
+    return 2 * g * g + 2 * 14 * n + (n + 4 * n + 1) + 8 * (n * n + 2 * n - 2)
+
+
+def cpu_baseline(pkg, kwargs, budget_s=12.0):
+    """The CPU oracle (kind "port": the C restatement pinned to the reference by tests/golden) timed on this
+    box's host cores on a bounded sample of the same workload: batches of arena envs x 200 steps of
+    step()+observe() with the same Philox action streams, OpenMP over envs, until ~budget_s has elapsed."""
+    import oracle  # test infrastructure: used here only as the reported CPU baseline
+
+    cfg, _ = pkg.config.build_config(kwargs, log_metrics=True)
+    # a 1-GPU box's CPU share is 16 cores; never more threads than the affinity mask allows
+    cores = int(os.environ.get("CTF_BENCH_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    steps = 200
+    t0 = time.perf_counter()
+    oracle.run_batch(cfg, 16, steps, 1_000_003, 7, True, 1)
+    one = 16 * steps / (time.perf_counter() - t0)  # single-thread rate from a pilot
+    batch, done_envs = cores * 16, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        oracle.run_batch(cfg, batch, steps, 1_000_003 + done_envs, 7, True, cores)
+        done_envs += batch
+    dt = time.perf_counter() - t0
+    return {
+        "value": done_envs * steps / dt,
+        "unit": "env-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{done_envs} envs x {steps} steps, 8_arena step()+observe(), C oracle, OpenMP over envs ({dt:.1f} s)",
+        "single_core_value": one,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--workload", choices=["arena", "split"], default="arena")
+    ap.add_argument("--no-metrics", action="store_true", help="compile the reference's metric counters out of the step kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--run", type=int, default=1, help="seed family: env seeds are 1_000_003*run + global env index")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    pkg = importlib.import_module("marl-ctf-development_amd")
+    sh = pkg.sharding
+    rank, local_rank, world = sh.world_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+    n_gpus = world
+
+    if args.workload == "arena":
+        kwargs = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+        label = "8_arena (arena_iii 15x15, 4v4 heterogeneous)"
+    else:
+        kwargs = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow)
+        label = "0_the_split (arrow 11x11, 2v2)"
+    E = args.envs_per_gpu
+    lo = rank * E
+    seeds = sh.env_seeds(args.run, lo, lo + E)
+    vec = pkg.VecGridworldCtf(E, device=local_rank, py_seeds=seeds, np_seeds=seeds, log_metrics=not args.no_metrics, **kwargs)
+    N, G, C = vec.N_AGENTS, vec.GRID_SIZE, vec.N_CHANNELS
+
+    K, W = args.steps, args.warmup
+    actions = torch.empty((W + K, E, N), dtype=torch.int8, device=device)
+    for t in range(W + K):
+        vec.random_actions(actions[t], seed=0xC7F, step=t, env_offset=lo)
+    gather = sh.RolloutGather(vec.rewards, vec.done, world)
+    vec.observe()
+
+    def one_step(t, events=None):
+        if events:
+            events[0].record()
+        rewards, done = vec.step(actions[t], auto_reset=True)
+        if events:
+            events[1].record()
+        gather.start(rewards, done)  # async RCCL all-gather of the compact rollout tensors (copy at N=1)
+        vec.observe()
+        if events:
+            events[2].record()
+
+    for t in range(W):
+        one_step(t)
+    gather.wait()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(K):
+        one_step(W + t, ev[t])
+    gather.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = sh.max_over_ranks(elapsed, device, world)
+    status = vec.status()
+
+    step_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    obs_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    if rank == 0:
+        value = n_gpus * E * K / elapsed
+        obs_bytes = observe_algorithmic_bytes(N, C, G) * E
+        achieved = obs_bytes / (obs_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.workload}_{E}", {}).get("k_observe_hbm_bytes_per_launch")
+        line = {
+            "metric": "env-steps/sec",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": n_gpus,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{label}, {E} envs/GPU resident in HBM, step()+observe() per env-step "
+                            f"(u8 obs [N={N}][C={C}][{G}][{G}], f16 metadata), Philox uniform actions, auto-reset at GAME_STEPS=500",
+                "envs_per_gpu": E,
+                "global_envs": n_gpus * E,
+                "metrics_counters": not args.no_metrics,
+                "rollout_exchange": "RCCL all-gather of rewards+done per step, async" if world > 1 else "none (1 GPU)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_observe",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_env": observe_algorithmic_bytes(N, C, G),
+                "avg_launch_ms": obs_ms,
+            },
+            "kernels_ms": {"k_step": step_ms, "k_observe": obs_ms},
+            "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (step_ms * 1e-3) / 1e9,
+            "device_status_bits": status,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pkg, kwargs)
+        print(json.dumps(line), flush=True)
+    vec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,6 @@ The directory name carries a hyphen, so import it with importlib::
 or, for drop-in use with the reference's own scripts, put this directory first on sys.path so that
 ``from gridworld_ctf import GridworldCtf`` resolves here.
 """
-from . import _abi, config, configs  # noqa: F401
+from . import _abi, config, configs, sharding  # noqa: F401
 from .gridworld_ctf import GridworldCtf, VecGridworldCtf  # noqa: F401
 from .maps import CtfScenarios  # noqa: F401

@@ -99,7 +99,8 @@ class CtfLibraryError(RuntimeError):
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libctf_hip.so")
+# CTF_LIB_PATH: profiling builds only (tools/ablate.sh); the default is the in-tree library
+LIB_PATH = os.environ.get("CTF_LIB_PATH") or os.path.join(_PKG_DIR, "csrc", "libctf_hip.so")
 
 # every symbol include/ctf_env.h declares: name -> (restype, argtypes)
 _P = C.c_void_p

@@ -124,7 +124,11 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     if (!make_fastdiv((uint32_t)d->CGG, (uint32_t)d->obs_bytes + 16, &d->div_cgg) ||
         !make_fastdiv((uint32_t)d->GG, (uint32_t)d->CGG + 16, &d->div_gg) ||
         !make_fastdiv((uint32_t)G, (uint32_t)d->GS + 4, &d->div_g) ||
-        !make_fastdiv((uint32_t)d->M, (uint32_t)(N * d->M) + 64, &d->div_m))
+        !make_fastdiv((uint32_t)d->M, (uint32_t)(N * d->M) + 64, &d->div_m) ||
+        !make_fastdiv((uint32_t)N, (uint32_t)(64 * N) + 64, &d->div_n) ||
+        !make_fastdiv((uint32_t)(d->GS / 16), (uint32_t)(64 * d->GS / 16) + 64, &d->div_gq) ||
+        !make_fastdiv((uint32_t)(d->RS / 16), (uint32_t)(64 * d->RS / 16) + 64, &d->div_rq) ||
+        !make_fastdiv((uint32_t)(CTF_N_METRICS * N), (uint32_t)(64 * CTF_N_METRICS * N) + 64, &d->div_mn))
         return fail(CTF_E_INVALID, "internal: reciprocal division not exact for these dimensions");
     d->heal = c->heal_per_step; d->tag_p = c->tag_probability; d->guard_mult = c->guardian_damage_multiplier;
     d->vault_cost = c->vault_hp_cost; d->vault_min = c->vault_min_hp;
@@ -139,6 +143,17 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     memcpy(d->spawn_pos, c->spawn_pos, sizeof(d->spawn_pos));
     memcpy(d->start_pos, c->start_pos, sizeof(d->start_pos));
     for (int i = 0; i < N; i++) d->default_reverse |= (c->agent_team[i] == 1) ? (1 << i) : 0;
+    for (int i = 0; i < N; i++) {
+        d->team_mask |= (uint32_t)c->agent_team[i] << i;
+        d->type_pack |= (uint32_t)c->agent_type[i] << (2 * i);
+        uint64_t idx = 15;
+        const int own = 1 - c->agent_team[i];  // OPPONENTS[1 - team] is the agent's own team
+        for (int k = c->n_opponents[own] - 1; k >= 0; k--)
+            if (c->opponents[own][k] == i) idx = (uint64_t)k;
+        d->self_idx_pack |= idx << (4 * i);
+    }
+    for (int t = 0; t < 2; t++)
+        for (int k = 0; k < c->n_opponents[t]; k++) d->opp_pack[t] |= (uint64_t)c->opponents[t][k] << (4 * k);
 
     // channel of every tile value as seen by a viewer of team t (reference gridworld_ctf.py:987-994: for a
     // team-1 viewer own/opponent agent tiles 4..7 <-> 8..11 and the flags 12 <-> 13 swap), 15 = no plane

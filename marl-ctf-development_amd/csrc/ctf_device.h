@@ -32,11 +32,16 @@ struct DevCfg {
     int32_t CGG, obs_bytes;         // C*G*G, N*C*G*G
     int32_t off_pos, off_flag, off_perm, off_inv, off_misc;  // record offsets (hp is at 0)
     int32_t default_reverse;        // bit i = (team(i) == 1)
-    FastDiv div_cgg, div_gg, div_g, div_m;
+    FastDiv div_cgg, div_gg, div_g, div_m, div_n, div_gq, div_rq, div_mn;
     double heal, tag_p, guard_mult, vault_cost, vault_min;
     double r_capture, r_step, r_tag, win_scalar, loss_scalar, punish;
     double type_hp[4], type_damage[4];
     uint64_t chan_lut[2];           // [viewer team]: nibble v = channel of tile v after relabelling, 15 = none
+    // lane-divergent lookups are bit-field extracts from these SGPR-resident packs (no memory access):
+    uint32_t team_mask;             // bit i = team(i)
+    uint32_t type_pack;             // 2 bits per agent
+    uint64_t opp_pack[2];           // nibble q of [t] = OPPONENTS[t][q]
+    uint64_t self_idx_pack;         // nibble i = index of agent i in its own team's list, 15 = not in it
     int8_t team[CTF_MAX_AGENTS], type[CTF_MAX_AGENTS];
     int8_t opp[2][CTF_MAX_AGENTS];
     int8_t flag_pos[2][2], capture_pos[2][2], spawn_pos[2][2];

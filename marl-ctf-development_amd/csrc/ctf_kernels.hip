@@ -30,61 +30,12 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// MT19937 with LAZY in-place regeneration: instead of rewriting all 624 words when the block is
-// exhausted (a 624-iteration burst that would serialise a divergent wave), word i of the next block
-// is produced from a[i], a[i+1], a[i+397] at the moment it is consumed.  Words [0,pos) then belong
-// to the new block and [pos,624) to the old one, which is exactly the order the standard in-place
-// algorithm visits them in, so the output stream is identical.  `lazy` is 0 only between a state
-// import (all words already tempered-ready) and the first wrap.
-struct Mt {
-    uint32_t* a;
-    uint32_t pos, lazy;
-};
-__device__ __forceinline__ Mt mt_open(uint32_t* base, uint32_t packed) {
-    Mt g;
-    g.a = base;
-    g.pos = packed & CTF_POS_MASK;
-    g.lazy = (packed & CTF_LAZY_BIT) ? 1u : 0u;
-    return g;
-}
-__device__ __forceinline__ uint32_t mt_close(const Mt& g) { return g.pos | (g.lazy ? CTF_LAZY_BIT : 0u); }
-__device__ __forceinline__ uint32_t mt_next(Mt& g) {
-    uint32_t i = g.pos;
-    if (i >= CTF_MT_N) { i = 0; g.lazy = 1; }
-    uint32_t v;
-    if (g.lazy) {
-        uint32_t i1 = (i + 1 == CTF_MT_N) ? 0u : i + 1;
-        uint32_t im = (i + 397 >= CTF_MT_N) ? i + 397 - CTF_MT_N : i + 397;
-        uint32_t y = (g.a[i] & 0x80000000u) | (g.a[i1] & 0x7fffffffu);
-        v = g.a[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        g.a[i] = v;
-    } else {
-        v = g.a[i];
-    }
-    g.pos = i + 1;
-    return mt_temper(v);
-}
-// CPython random._randbelow_with_getrandbits(n): k = n.bit_length(); draw k bits until < n
-__device__ __forceinline__ uint32_t py_randbelow(Mt& g, uint32_t n) {
-    uint32_t sh = (uint32_t)__clz((int)n);  // 32 - bit_length
-    uint32_t r = mt_next(g) >> sh;
-    while (r >= n) r = mt_next(g) >> sh;
-    return r;
-}
-// NumPy legacy random_sample()
-__device__ __forceinline__ double np_rand(Mt& g) {
-    uint32_t a = mt_next(g) >> 5, b = mt_next(g) >> 6;
-    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
-}
-// NumPy legacy randint(k), k >= 1: masked rejection on one 32-bit word; k == 1 draws nothing
-__device__ __forceinline__ uint32_t np_randint(Mt& g, uint32_t k) {
-    uint32_t rng = k - 1;
-    if (rng == 0) return 0;
-    uint32_t mask = 0xFFFFFFFFu >> __clz((int)rng);
-    uint32_t v;
-    do { v = mt_next(g) & mask; } while (v > rng);
-    return v;
-}
+// MT19937 with LAZY in-place regeneration (used by MtWin below): instead of rewriting all 624 words when
+// the block is exhausted (a 624-iteration burst that would serialise a divergent wave), word i of the
+// next block is produced from a[i], a[i+1], a[i+397] at the moment it is consumed.  Words [0,pos) then
+// belong to the new block and [pos,624) to the old one, which is exactly the order the standard in-place
+// algorithm visits them in, so the output stream is identical.  The lazy flag is 0 only between a state
+// import (words [pos,624) are output as they stand) and the first wrap.
 
 // NumPy npy_double_to_half: direct round-to-nearest-even f64 -> binary16 bits
 __device__ __forceinline__ uint16_t f64_to_f16(double d) {
@@ -199,20 +150,137 @@ extern "C" __global__ void __launch_bounds__(WAVE) k_reset(DevCfg cfg, DevPtrs p
 }
 
 // ------------------------------------------------------------------------------------------------
+// lane-divergent config lookups: bit-field extracts / selects on SGPR-resident values (no memory traffic)
+// ------------------------------------------------------------------------------------------------
+// pin*(): pass a kernel-argument value through readfirstlane so that it is an opaque SGPR value.  Without
+// this the compiler rewrites "team ? cfg.x[1] : cfg.x[0]" into ONE load from a lane-selected kernarg
+// address, i.e. a dependent vector-memory access in the middle of the per-agent loop.
+__device__ __forceinline__ int pin(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t pin64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double pind(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int cfg_team(const DevCfg& c, int a) { return (int)(((uint32_t)pin((int)c.team_mask) >> a) & 1u); }
+__device__ __forceinline__ int cfg_type(const DevCfg& c, int a) { return (int)(((uint32_t)pin((int)c.type_pack) >> (2 * a)) & 3u); }
+__device__ __forceinline__ int cfg_opp(const DevCfg& c, int team, int q) {
+    const uint64_t p0 = pin64(c.opp_pack[0]), p1 = pin64(c.opp_pack[1]);
+    return (int)(((team ? p1 : p0) >> (4 * q)) & 15u);
+}
+__device__ __forceinline__ int cfg_nopp(const DevCfg& c, int team) { return team ? pin(c.n_opp[1]) : pin(c.n_opp[0]); }
+__device__ __forceinline__ double sel4(const double* t, int k) {
+    const double t0 = pind(t[0]), t1 = pind(t[1]), t2 = pind(t[2]), t3 = pind(t[3]);
+    return k == 0 ? t0 : (k == 1 ? t1 : (k == 2 ? t2 : t3));
+}
+#define TSEL(arr, team, k) ((team) ? pin((int)(arr)[1][k]) : pin((int)(arr)[0][k]))
+
+// ------------------------------------------------------------------------------------------------
 // step — one lane per env, 64 envs per 64-thread block, state staged through LDS
 // ------------------------------------------------------------------------------------------------
-// LDS slot of one env (bytes): [grid GS][rec RS][actions 16][metric deltas u16 13*N (METRICS)] ; the slot
-// stride in dwords is odd so that the 64 lanes' same-offset accesses fall in distinct banks.
+// LDS slot of one env (bytes):
+//   [grid GS][rec RS][actions 16][py window 64][np window 64][metric deltas u8 13*N (METRICS)]
+// The slot stride in dwords is odd so that the 64 lanes' same-offset accesses fall in distinct banks.
+#define WCAP 16  // MT words per refill of a stream's window
+
 __host__ __device__ inline int step_slot_bytes(int GS, int RS, int N, bool metrics) {
-    int b = GS + RS + 16 + (metrics ? ((CTF_N_METRICS * N * 2 + 3) & ~3) : 0);
+    int b = GS + RS + 16 + 2 * WCAP * 4 + (metrics ? ((CTF_N_METRICS * N + 3) & ~3) : 0);
     if (((b / 4) & 1) == 0) b += 4;
     return b;
 }
 
+// One MT19937 stream of one env: state words in HBM, a small window of the next words in LDS.
+// Lazy in-place regeneration (see Mt above); a refill issues all its loads back to back, so a step pays
+// one exposed memory latency per WCAP words instead of one per word.
+struct MtWin {
+    uint32_t* a;    // 624 state words (global)
+    uint32_t* win;  // WCAP untempered words, already regenerated (LDS)
+    uint32_t pos;   // stream position of win[0]
+    uint32_t lazy;
+    uint32_t n, cur;
+};
+__device__ __forceinline__ MtWin mtw_open(uint32_t* base, uint32_t* win, uint32_t packed) {
+    MtWin g;
+    g.a = base; g.win = win;
+    g.pos = packed & CTF_POS_MASK;
+    g.lazy = (packed & CTF_LAZY_BIT) ? 1u : 0u;
+    g.n = 0; g.cur = 0;
+    return g;
+}
+// write the consumed, regenerated words back and advance; unconsumed window words are simply dropped
+// (they are recomputed from unchanged state words on the next refill)
+__device__ __forceinline__ void mtw_flush(MtWin& g) {
+    if (g.lazy)
+        for (uint32_t j = 0; j < g.cur; j++) g.a[g.pos + j] = g.win[j];
+    g.pos += g.cur;
+    g.n = 0; g.cur = 0;
+}
+__device__ __forceinline__ uint32_t mtw_close(MtWin& g) {
+    mtw_flush(g);
+    return g.pos | (g.lazy ? CTF_LAZY_BIT : 0u);
+}
+__device__ __forceinline__ void mtw_refill(MtWin& g) {
+    if (g.pos >= CTF_MT_N) { g.pos = 0; g.lazy = 1; }
+    const uint32_t want = min((uint32_t)WCAP, (uint32_t)CTF_MT_N - g.pos);
+    uint32_t x[WCAP + 1], m[WCAP];
+#pragma unroll
+    for (int j = 0; j <= WCAP; j++) {
+        const uint32_t i = g.pos + j;
+        x[j] = ((uint32_t)j <= want) ? g.a[i == CTF_MT_N ? 0u : i] : 0u;
+    }
+    if (g.lazy) {
+#pragma unroll
+        for (int j = 0; j < WCAP; j++) {
+            const uint32_t i = g.pos + j;
+            m[j] = ((uint32_t)j < want) ? g.a[i + 397 >= CTF_MT_N ? i + 397 - CTF_MT_N : i + 397] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < WCAP; j++) {
+            const uint32_t y = (x[j] & 0x80000000u) | (x[j + 1] & 0x7fffffffu);
+            g.win[j] = m[j] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WCAP; j++) g.win[j] = x[j];
+    }
+    g.n = want; g.cur = 0;
+}
+__device__ __forceinline__ uint32_t mtw_next(MtWin& g) {
+    if (g.cur == g.n) { mtw_flush(g); mtw_refill(g); }
+    return mt_temper(g.win[g.cur++]);
+}
+// (each helper holds exactly ONE inlined copy of the refill code: keep the loops rolled)
+__device__ __forceinline__ uint32_t py_randbelow(MtWin& g, uint32_t n) {
+    const uint32_t sh = (uint32_t)__clz((int)n);  // 32 - n.bit_length()
+    uint32_t r;
+    do { r = mtw_next(g) >> sh; } while (r >= n);
+    return r;
+}
+__device__ __forceinline__ double np_rand(MtWin& g) {
+    uint32_t a = 0, b = 0;
+#pragma unroll 1
+    for (int t = 0; t < 2; t++) {
+        const uint32_t v = mtw_next(g);
+        if (t == 0) a = v >> 5;
+        else b = v >> 6;
+    }
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ uint32_t np_randint(MtWin& g, uint32_t k) {
+    const uint32_t rng = k - 1;
+    if (rng == 0) return 0;  // randint(1) draws nothing
+    const uint32_t mask = 0xFFFFFFFFu >> __clz((int)rng);
+    uint32_t v;
+    do { v = mtw_next(g) & mask; } while (v > rng);
+    return v;
+}
+
 struct StepCtx {
-    uint8_t* sg;   // grid  (LDS)
-    uint8_t* sr;   // record (LDS)
-    uint16_t* sm;  // metric deltas (LDS) or nullptr
+    uint8_t* sg;  // grid  (LDS)
+    uint8_t* sr;  // record (LDS)
+    uint8_t* sm;  // metric deltas of this step (LDS) or nullptr
 };
 
 __device__ __forceinline__ double ld_hp(const StepCtx& s, int a) {
@@ -227,47 +295,45 @@ __device__ __forceinline__ void st_hp(const StepCtx& s, int a, double v) {
 
 template <bool METRICS>
 __device__ __forceinline__ void metric_add(const DevCfg& cfg, const StepCtx& s, int m, int a, int v) {
-    if (METRICS) s.sm[m * cfg.N + a] += (uint16_t)v;
+    if (METRICS) s.sm[m * cfg.N + a] += (uint8_t)v;  // per-step deltas stay far below 256
 }
 
 // respawn, gridworld_ctf.py:761-794
-__device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx& s, Mt& np_, int o, uint32_t& status) {
-    const int G = cfg.G, team = cfg.team[o];
-    const int x = cfg.spawn_pos[team][0], y = cfg.spawn_pos[team][1];
+__device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx& s, MtWin& np_, int o, uint32_t& status) {
+    const int G = cfg.G, team = cfg_team(cfg, o), type = cfg_type(cfg, o);
+    const int x = TSEL(cfg.spawn_pos, team, 0), y = TSEL(cfg.spawn_pos, team, 1);
     const int r0 = x - 1 > 0 ? x - 1 : 0, c0 = y - 1 > 0 ? y - 1 : 0;
     const int r1 = x + 2 < G ? x + 2 : G, c1 = y + 2 < G ? y + 2 : G;
     // open cells of the (clipped) 3x3 window as a bitmask in row-major candidate order
     uint32_t open = 0;
     int k = 0;
     for (int r = r0; r < r1; r++)
-        for (int c = c0; c < c1; c++) {
+        for (int c = c0; c < c1; c++)
             if (s.sg[r * G + c] == 0) { open |= 1u << ((r - r0) * 3 + (c - c0)); k++; }
-        }
     if (k == 0) { status |= CTF_ST_NO_RESPAWN; return; }
-    uint32_t rnd = np_randint(np_, (uint32_t)k);
-    // rnd-th set bit
+    const uint32_t rnd = np_randint(np_, (uint32_t)k);
     uint32_t bits = open;
-    for (uint32_t t = 0; t < rnd; t++) bits &= bits - 1;
-    int sel = __ffs((int)bits) - 1;
+    for (uint32_t t = 0; t < rnd; t++) bits &= bits - 1;  // drop the rnd lowest candidates
+    const int sel = __ffs((int)bits) - 1;
     int nr = x + sel / 3 - 1, nc = y + sel % 3 - 1;  // "-1" even when the window was clipped (:775)
     if (nr < 0 || nc < 0) { status |= CTF_ST_SPAWN_EDGE; nr = nr < 0 ? nr + G : nr; nc = nc < 0 ? nc + G : nc; }
     int8_t* ps = (int8_t*)(s.sr + cfg.off_pos);
     const int orow = ps[2 * o], ocol = ps[2 * o + 1];
     s.sg[orow * G + ocol] = 0;
-    s.sg[nr * G + nc] = (uint8_t)(4 + cfg.type[o] + 4 * team);
+    s.sg[nr * G + nc] = (uint8_t)(4 + type + 4 * team);
     ps[2 * o] = (int8_t)nr;
     ps[2 * o + 1] = (int8_t)nc;
-    st_hp(s, o, cfg.type_hp[cfg.type[o]]);
+    st_hp(s, o, sel4(cfg.type_hp, type));
     if (s.sr[cfg.off_flag + o]) {
         s.sr[cfg.off_flag + o] = 0;
         if (cfg.drop_flag) s.sg[orow * G + ocol] = (uint8_t)(12 + (1 - team));
-        else s.sg[cfg.flag_pos[1 - team][0] * G + cfg.flag_pos[1 - team][1]] = (uint8_t)(12 + (1 - team));
+        else s.sg[TSEL(cfg.flag_pos, 1 - team, 0) * G + TSEL(cfg.flag_pos, 1 - team, 1)] = (uint8_t)(12 + (1 - team));
     }
 }
 
 // The body of GridworldCtf.step for ONE env whose state sits in LDS.  Returns rewards through `rw`.
 template <bool METRICS>
-__device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, const int8_t* act, Mt& py, Mt& np_,
+__device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, const int8_t* act, MtWin& py, MtWin& np_,
                                          uint32_t& status, double* rw /*[CTF_MAX_AGENTS], statically indexed*/) {
     const int N = cfg.N, G = cfg.G;
     int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
@@ -279,26 +345,28 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, co
     misc[0] += 1;  // env_step_count
     uint32_t cap_mask = 0, resp_mask = 0, cap_team = 0;
 
-    // dice_roll (:734-742): random.shuffle(self._arr)
-    for (int i = N - 1; i >= 1; i--) {
-        uint32_t j = py_randbelow(py, (uint32_t)i + 1u);
-        uint8_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    // Two shuffles per step: dice_roll (:734-742) before the agents act and the one inside heal_agents
+    // (:839-847) after.  One rolled loop holds both so that the RNG refill code exists once.
+#pragma unroll 1
+    for (int phase = 0; phase < 2; phase++) {
+#pragma unroll 1
+    for (int i = N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
+        const uint32_t j = py_randbelow(py, (uint32_t)i + 1u);
+        const uint8_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
     }
+    if (phase == 1) break;
 
     for (int k = 0; k < N; k++) {
         const int a = perm[k];
-        const int type = cfg.type[a], team = cfg.team[a];
+        const int type = cfg_type(cfg, a), team = cfg_team(cfg, a);
         int action = act[a];
         if (action < 0 || action >= CTF_N_ACTIONS) { status |= CTF_ST_BAD_ACTION; action = 4; }
 
-        // ---- act (:700-732)
-        int dr = 0, dc = 0;
-        {
-            const int base = action <= 4 ? action : action - 5;
-            const int scale = action <= 4 ? 1 : (type == 2 ? 2 : (type == 3 ? 1 : 0));
-            dr = (base == 0 ? -1 : (base == 1 ? 1 : 0)) * scale;
-            dc = (base == 2 ? 1 : (base == 3 ? -1 : 0)) * scale;
-        }
+        // ---- act (:700-732); ACTION_DELTAS (:100-145): vaulter jumps 2, miner acts at distance 1 on 5..8
+        const int base = action <= 4 ? action : action - 5;
+        const int scale = action <= 4 ? 1 : (type == 2 ? 2 : (type == 3 ? 1 : 0));
+        const int dr = (base == 0 ? -1 : (base == 1 ? 1 : 0)) * scale;
+        const int dc = (base == 2 ? 1 : (base == 3 ? -1 : 0)) * scale;
         int pr = ps[2 * a], pc = ps[2 * a + 1];
         const int nr = pr + dr, nc = pc + dc;
         if (nr >= 0 && nr < G && nc >= 0 && nc < G) {
@@ -310,8 +378,8 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, co
                 pr = nr; pc = nc;
                 ps[2 * a] = (int8_t)nr;
                 ps[2 * a + 1] = (int8_t)nc;
-                const int ofr = cfg.flag_pos[1 - team][0], ofc = cfg.flag_pos[1 - team][1];
-                const int hfr = cfg.flag_pos[team][0], hfc = cfg.flag_pos[team][1];
+                const int ofr = TSEL(cfg.flag_pos, 1 - team, 0), ofc = TSEL(cfg.flag_pos, 1 - team, 1);
+                const int hfr = TSEL(cfg.flag_pos, team, 0), hfc = TSEL(cfg.flag_pos, team, 1);
                 if (cheb(nr, nc, ofr, ofc) <= 1 && s.sg[ofr * G + ofc] == 12 + (1 - team)) {  // pickup: flag cell -> BLOCK
                     flag[a] = 1;
                     s.sg[ofr * G + ofc] = 1;
@@ -329,16 +397,16 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, co
                 }
                 if (action >= 5 && type == 2) st_hp(s, a, ld_hp(s, a) - cfg.vault_cost);  // update_vaulter_hp
             } else if (action >= 5 && type == 3 && inv[a] > 0 && cell == 0 &&
-                       cheb(nr, nc, cfg.spawn_pos[team][0], cfg.spawn_pos[team][1]) > 1 &&
-                       cheb(nr, nc, cfg.spawn_pos[1 - team][0], cfg.spawn_pos[1 - team][1]) > 1) {
+                       cheb(nr, nc, TSEL(cfg.spawn_pos, team, 0), TSEL(cfg.spawn_pos, team, 1)) > 1 &&
+                       cheb(nr, nc, TSEL(cfg.spawn_pos, 1 - team, 0), TSEL(cfg.spawn_pos, 1 - team, 1)) > 1) {
                 s.sg[nr * G + nc] = 2;  // add_block (:614-634)
                 inv[a] -= 1;
                 if (METRICS) {
                     metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID, a, 1);
                     metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OWN_FLAG, a,
-                                        cheb(pr, pc, cfg.capture_pos[team][0], cfg.capture_pos[team][1]));
+                                        cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)));
                     metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OPP_FLAG, a,
-                                        cheb(pr, pc, cfg.capture_pos[1 - team][0], cfg.capture_pos[1 - team][1]));
+                                        cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)));
                 }
             } else if (action < 5 && type == 3 && (cell == 2 || cell == 3)) {
                 if (cell == 2) {
@@ -352,14 +420,14 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, co
         }
 
         // ---- tagging_logic (:796-837)
-        const double dmg = cfg.type_damage[type];
+        const double dmg = sel4(cfg.type_damage, type);
         if (dmg > 0) {
             double mult = 1.0;
-            if (type == 1 && cheb(pr, pc, cfg.flag_pos[team][0], cfg.flag_pos[team][1]) <= 3) mult = cfg.guard_mult;
+            if (type == 1 && cheb(pr, pc, TSEL(cfg.flag_pos, team, 0), TSEL(cfg.flag_pos, team, 1)) <= 3) mult = cfg.guard_mult;
             const double hit = dmg * mult;
-            const int no = cfg.n_opp[team];
+            const int no = cfg_nopp(cfg, team);
             for (int q = 0; q < no; q++) {
-                const int o = cfg.opp[team][q];
+                const int o = cfg_opp(cfg, team, q);
                 const double u = np_rand(np_);  // drawn first, unconditionally
                 if (u < cfg.tag_p && cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1) {
                     const double h = ld_hp(s, o) - hit;
@@ -377,31 +445,31 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, co
 
         // ---- metric-only section (:879-902)
         if (METRICS) {
-            if (cheb(pr, pc, cfg.capture_pos[team][0], cfg.capture_pos[team][1]) <= 3)
+            if (cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)) <= 3)
                 metric_add<METRICS>(cfg, s, CTF_M_STEPS_DEFENDING_ZONE, a, 1);
-            if (cheb(pr, pc, cfg.capture_pos[1 - team][0], cfg.capture_pos[1 - team][1]) <= 3)
+            if (cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)) <= 3)
                 metric_add<METRICS>(cfg, s, CTF_M_STEPS_ATTACKING_ZONE, a, 1);
             int adj = 0;
-            for (int q = 0; q < cfg.n_opp[1 - team]; q++) {  // OPPONENTS[1-team]: own team, self included
-                const int m = cfg.opp[1 - team][q];
+            const int n_own = cfg_nopp(cfg, 1 - team);
+            for (int q = 0; q < n_own; q++) {  // OPPONENTS[1-team]: own team, self included
+                const int m = cfg_opp(cfg, 1 - team, q);
                 adj += cheb(pr, pc, ps[2 * m], ps[2 * m + 1]) <= 1;
             }
             metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_TEAMMATE, a, adj);
             adj = 0;
-            for (int q = 0; q < cfg.n_opp[team]; q++) {
-                const int o = cfg.opp[team][q];
+            const int n_opp = cfg_nopp(cfg, team);
+            for (int q = 0; q < n_opp; q++) {
+                const int o = cfg_opp(cfg, team, q);
                 adj += cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1;
             }
             metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_OPPONENT, a, adj);
         }
     }
 
-    // heal_agents (:839-847): a second shuffle (consumes RNG, mutates _arr), then heal everyone
-    for (int i = N - 1; i >= 1; i--) {
-        uint32_t j = py_randbelow(py, (uint32_t)i + 1u);
-        uint8_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
-    }
-    for (int a = 0; a < N; a++) {
+    }  // phase
+
+    // heal_agents (:839-847), after its shuffle above: heal everyone (order is irrelevant to the result)
+    for (int a = 0; a < N; a++) {  // uniform index: scalar table loads
         const double mx = cfg.type_hp[cfg.type[a]];
         double h = ld_hp(s, a);
         if (h < mx) {
@@ -446,39 +514,58 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
     const int nvalid = min(WAVE, cfg.n_envs - env0);
     const int SLB = step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     const int SLW = SLB / 4, GW = cfg.GS / 4, RW = cfg.RS / 4;
-    const int AW = 4;  // action words per slot
+    const int AW = 4, WW = 2 * WCAP;  // action words, RNG window words per slot
     const int N = cfg.N;
+    const int e = env0 + lane;
 
-    // ---- stage 64 envs' grids, records and actions into LDS (coalesced: one env per iteration)
+    // ---- stage 64 envs' grids, records and actions into LDS.  Flat, coalesced 16-byte loads, unrolled
+    // so that every lane has 8 independent loads in flight (a rolled per-env loop pays one full memory
+    // latency per env: measured 130 us of a 250 us kernel).
     {
-        const uint32_t* gsrc = (const uint32_t*)(p.grid + (size_t)env0 * cfg.GS);
-        const uint32_t* rsrc = (const uint32_t*)(p.rec + (size_t)env0 * cfg.RS);
-        for (int el = 0; el < nvalid; el++) {
-            uint32_t* slot = lds + el * SLW;
-            for (int w = lane; w < GW; w += WAVE) slot[w] = gsrc[el * GW + w];
-            for (int w = lane; w < RW; w += WAVE) slot[GW + w] = rsrc[el * RW + w];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* gsrc = (const u32x4*)(p.grid + (size_t)env0 * cfg.GS);
+        const u32x4* rsrc = (const u32x4*)(p.rec + (size_t)env0 * cfg.RS);
+        const int GQ = GW / 4, RQ = RW / 4;  // 16-byte quads per env (GS and RS are multiples of 16)
+        const int ng = nvalid * GQ, nr = nvalid * RQ;
+#pragma unroll 8
+        for (int q = lane; q < ng; q += WAVE) {
+            const u32x4 v = gsrc[q];
+            const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
+            uint32_t* slot = lds + el * SLW + w;
+            slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
+        }
+#pragma unroll 8
+        for (int q = lane; q < nr; q += WAVE) {
+            const u32x4 v = rsrc[q];
+            const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
+            uint32_t* slot = lds + el * SLW + GW + w;
+            slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
         }
         const int8_t* asrc = actions + (size_t)env0 * N;
+#pragma unroll 4
         for (int idx = lane; idx < nvalid * N; idx += WAVE) {
-            int el = idx / N, i = idx - el * N;
+            const int el = (int)fdiv((uint32_t)idx, cfg.div_n), i = idx - el * N;
             ((int8_t*)(lds + el * SLW + GW + RW))[i] = asrc[idx];
         }
         if (METRICS) {
-            const int MW = (CTF_N_METRICS * N * 2 + 3) / 4;
+            const int MW = (CTF_N_METRICS * N + 3) / 4;
             for (int el = 0; el < nvalid; el++)
-                for (int w = lane; w < MW; w += WAVE) lds[el * SLW + GW + RW + AW + w] = 0;
+                for (int w = lane; w < MW; w += WAVE) lds[el * SLW + GW + RW + AW + WW + w] = 0;
         }
     }
     __syncthreads();
 
-    const int e = env0 + lane;
     if (lane < nvalid) {
         StepCtx s;
         s.sg = (uint8_t*)(lds + lane * SLW);
         s.sr = s.sg + cfg.GS;
-        s.sm = METRICS ? (uint16_t*)(s.sr + cfg.RS + 16) : nullptr;
+        uint32_t* wins = (uint32_t*)(s.sr + cfg.RS + 16);
+        s.sm = METRICS ? (uint8_t*)(wins + WW) : nullptr;
         const int8_t* act = (const int8_t*)(s.sr + cfg.RS);
         int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
+
+        MtWin py = mtw_open(p.mt_py + (size_t)e * CTF_MT_N, wins, p.rngpos[2 * e]);
+        MtWin npg = mtw_open(p.mt_np + (size_t)e * CTF_MT_N, wins + WCAP, p.rngpos[2 * e + 1]);
 
         if ((flags & CTF_STEP_AUTO_RESET) && misc[3]) {
             // reset() of this env inside the step launch (not in the reference: opt-in flag)
@@ -494,13 +581,11 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
             }
         }
 
-        Mt py = mt_open(p.mt_py + (size_t)e * CTF_MT_N, p.rngpos[2 * e]);
-        Mt npg = mt_open(p.mt_np + (size_t)e * CTF_MT_N, p.rngpos[2 * e + 1]);
         uint32_t status = 0;
         double rw[CTF_MAX_AGENTS];
         env_step<METRICS>(cfg, s, act, py, npg, status, rw);
-        p.rngpos[2 * e] = mt_close(py);
-        p.rngpos[2 * e + 1] = mt_close(npg);
+        p.rngpos[2 * e] = mtw_close(py);
+        p.rngpos[2 * e + 1] = mtw_close(npg);
         if (status) atomicOr(p.status, status);
 
 #pragma unroll
@@ -520,40 +605,67 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
     }
     __syncthreads();
 
-    // ---- write the 64 envs back (coalesced)
+    // ---- write the 64 envs back (flat, coalesced 16-byte stores)
     {
-        uint32_t* gdst = (uint32_t*)(p.grid + (size_t)env0 * cfg.GS);
-        uint32_t* rdst = (uint32_t*)(p.rec + (size_t)env0 * cfg.RS);
-        for (int el = 0; el < nvalid; el++) {
-            const uint32_t* slot = lds + el * SLW;
-            for (int w = lane; w < GW; w += WAVE) gdst[el * GW + w] = slot[w];
-            for (int w = lane; w < RW; w += WAVE) rdst[el * RW + w] = slot[GW + w];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* gdst = (u32x4*)(p.grid + (size_t)env0 * cfg.GS);
+        u32x4* rdst = (u32x4*)(p.rec + (size_t)env0 * cfg.RS);
+        const int GQ = GW / 4, RQ = RW / 4;
+        const int ng = nvalid * GQ, nr = nvalid * RQ;
+#pragma unroll 4
+        for (int q = lane; q < ng; q += WAVE) {
+            const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
+            const uint32_t* slot = lds + el * SLW + w;
+            const u32x4 v = {slot[0], slot[1], slot[2], slot[3]};
+            gdst[q] = v;
+        }
+#pragma unroll 4
+        for (int q = lane; q < nr; q += WAVE) {
+            const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
+            const uint32_t* slot = lds + el * SLW + GW + w;
+            const u32x4 v = {slot[0], slot[1], slot[2], slot[3]};
+            rdst[q] = v;
         }
         if (METRICS) {
+            // this step's u8 deltas are added to the i32 counters with no-return atomics: nothing to wait for
             const int MN = CTF_N_METRICS * N;
             int32_t* mdst = p.metrics + (size_t)env0 * MN;
-            for (int el = 0; el < nvalid; el++) {
-                const uint16_t* d = (const uint16_t*)(lds + el * SLW + GW + RW + AW);
-                for (int w = lane; w < MN; w += WAVE) {
-                    uint16_t inc = d[w];
-                    if (inc) mdst[el * MN + w] += inc;
-                }
+            for (int idx = lane; idx < nvalid * MN; idx += WAVE) {
+                const int el = (int)fdiv((uint32_t)idx, cfg.div_mn), w = idx - el * MN;
+                const uint8_t inc = ((const uint8_t*)(lds + el * SLW + GW + RW + AW + WW))[w];
+                if (inc) atomicAdd(mdst + idx, (int32_t)inc);
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// observe — one wave per env at a time; 16 output bytes per lane per iteration
+// observe — one wave per env at a time; the env's whole one-hot block is first built as a BITMAP in LDS
 // ------------------------------------------------------------------------------------------------
-// Per-wave LDS (bytes): [rec RS][aginfo 16 x u32][4 view slots x VS] ; a view slot holds, for one
-// (viewer team, reversed?) combination, the channel code of every cell in the view's orientation,
-// twice: codes[0..GG) followed by codes[0..GG) - 1.  A 16-byte output chunk that starts in plane c at
-// cell0 and runs into plane c+1 is then simply 16 consecutive bytes of the slot compared with c.
-__host__ __device__ inline int obs_view_bytes(int GG) { return (2 * GG + 8 + 3) & ~3; }
-__host__ __device__ inline int obs_wave_bytes(int RS, int GG) { return RS + 64 + 4 * obs_view_bytes(GG); }
+// The observation block u8 [N][C][G][G] of one env is ~98 % zeros.  Per env a wave
+//   1. zeroes a bitmap of N*C*G*G bits in LDS (one bit per output byte),
+//   2. sets the hot bits: for every non-empty grid cell and every agent, bit
+//      i*C*G*G + channel(viewer team, tile)*G*G + (reversed ? flip(cell) : cell), plus the own-position
+//      bit of plane 0 — LDS atomic ORs, relabelling via the SGPR-resident channel LUT,
+//   3. streams the block out: 16-byte chunk k of the output is halfword k of the bitmap with every bit
+//      expanded to a byte (3 full-rate VALU ops per 4 bytes), one 1-KiB-aligned coalesced store
+//      instruction per 64 chunks.
+// Metadata rows (f16 [N][2N+6]) are assembled in LDS and leave as 8-byte stores.
+//
+// Per-wave LDS (bytes): [rec RS][mvals 96][meta staging][bitmap]
+#define OBS_MV_BYTES 96
+__host__ __device__ inline int obs_meta_stage_bytes(int N, int M) { return (N * M * 2 + 15) & ~15; }
+__host__ __device__ inline int obs_bitmap_bytes(int obs_bytes) { return ((((obs_bytes + 31) / 32 + 1) * 4) + 15) & ~15; }
+__host__ __device__ inline int obs_wave_bytes(int RS, int N, int M, int obs_bytes) {
+    return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_bitmap_bytes(obs_bytes);
+}
 
-#define OBS_WAVES 4
+#define LGKM_ONLY 0xC07F  // s_waitcnt lgkmcnt(0): LDS traffic only — never drain the wave's outstanding stores
+// Profiling-only ablations (never defined in the shipped build; see tools/ablate.sh):
+//   bit0 no bit expansion, bit1 no chunk stores, bit2 no bitmap build, bit3 no metadata
+#ifndef OBS_ABLATE
+#define OBS_ABLATE 0
+#endif
 
 template <int ALIGN>
 struct OutVec;
@@ -561,153 +673,210 @@ template <>
 struct OutVec<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
 template <>
 struct OutVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4), aligned(4))); };
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int flip_cell(const DevCfg& cfg, int cell, int r, int c) {
+    // destination of cell (r, c) under reverse_grid (gridworld_ctf.py:1003-1007)
+    const int G = cfg.G;
+    if (cfg.flip_axis == -1) return cfg.GG - 1 - cell;      // np.flip over both axes
+    if (cfg.flip_axis == 0) return (G - 1 - r) * G + c;     // np.flip(plane, 0)
+    if (cfg.flip_axis == 1) return r * G + (G - 1 - c);     // np.flip(plane, 1)
+    return (G - 1 - c) * G + (G - 1 - r);                   // np.rot90(plane.T, 2)
+}
+// A load the compiler does not track: issued one env ahead of its use, waited for by obs_prefetch_wait.
+// (vmcnt retires in issue order, so a compiler-placed wait for next env's state would first drain every
+// store of the current env; issued BEFORE those stores and waited for with a counted vmcnt a few
+// stores later, the data is simply there when the wave reaches the next env.)
+__device__ __forceinline__ uint32_t obs_prefetch_dword(const uint32_t* ptr) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+#define OBS_PF_WAIT 10  // stream iteration at which the prefetched state is waited for ...
+// ... with vmcnt(8): the two prefetch loads are older than the >= OBS_PF_WAIT stores issued since
+#define OBS_PREFETCH_WAIT(a, b) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a), "+v"(b)::"memory")
+#define OBS_PREFETCH_DRAIN(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory")
+
+// 4 bits -> 4 bytes of 0/1: the four shifted copies of the nibble do not overlap, so no carries
+__device__ __forceinline__ uint32_t expand4(uint32_t h, int j) {
+    return (((h >> (4 * j)) & 15u) * 0x00204081u) & 0x01010101u;
+}
 
 template <int ALIGN>
-__global__ void __launch_bounds__(OBS_WAVES* WAVE) k_observe(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs,
-                                                              uint16_t* __restrict__ meta, uint32_t reverse_mask) {
+__global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs,
+                                                 uint16_t* __restrict__ meta, uint32_t reverse_mask) {
     extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    const int N = cfg.N, G = cfg.G, GG = cfg.GG, C = cfg.C;
-    const int VS = obs_view_bytes(GG);
-    uint8_t* wl = (uint8_t*)lds + wave * obs_wave_bytes(cfg.RS, GG);
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int wpb = blockDim.x / WAVE;
+    const int N = cfg.N, G = cfg.G, GG = cfg.GG, M = cfg.M;
+    uint8_t* wl = (uint8_t*)lds + wave * obs_wave_bytes(cfg.RS, N, M, cfg.obs_bytes);
     uint8_t* srec = wl;
-    uint32_t* aginfo = (uint32_t*)(wl + cfg.RS);
-    uint8_t* views = wl + cfg.RS + 64;
-    // which (team, reversed) view slots are needed — uniform over the launch
-    uint32_t need = 0;
-    for (int i = 0; i < N; i++) need |= 1u << (cfg.team[i] * 2 + ((reverse_mask >> i) & 1u));
+    uint16_t* mv = (uint16_t*)(wl + cfg.RS);
+    uint16_t* mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
+    uint32_t* bits = (uint32_t*)(wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M));
+    const int BQ = obs_bitmap_bytes(cfg.obs_bytes) / 16;
+    // agents per (viewer team, reversed?) view slot — uniform over the launch
+    uint32_t slot_agents[4] = {0, 0, 0, 0};
+    for (int i = 0; i < N; i++) {
+        const int sl = cfg.team[i] * 2 + (int)((reverse_mask >> i) & 1u);
+        slot_agents[0] |= (sl == 0) ? (1u << i) : 0u;
+        slot_agents[1] |= (sl == 1) ? (1u << i) : 0u;
+        slot_agents[2] |= (sl == 2) ? (1u << i) : 0u;
+        slot_agents[3] |= (sl == 3) ? (1u << i) : 0u;
+    }
 
-    for (int e = blockIdx.x * OBS_WAVES + wave; e < cfg.n_envs; e += gridDim.x * OBS_WAVES) {
-        // ---- record -> LDS
-        {
-            const uint32_t* rsrc = (const uint32_t*)(p.rec + (size_t)e * cfg.RS);
-            for (int w = lane; w < cfg.RS / 4; w += WAVE) ((uint32_t*)srec)[w] = rsrc[w];
-        }
-        // ---- build the view slots: every lane relabels + scatters 4 cells per pass
+    const bool has_cells = obs && !(OBS_ABLATE & 4);
+    const int GW = cfg.GS / 4;  // <= 256 dwords: up to 4 passes of 64 lanes
+    const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
+    const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
+    // the first env's state: ordinary loads; every later env's state arrives through the prefetch below
+    uint32_t recw = 0, cells = 0;
+    if (e_first < cfg.n_envs) {
+        recw = ((const uint32_t*)(p.rec + (size_t)e_first * cfg.RS))[rec_lane];
+        cells = ((const uint32_t*)(p.grid + (size_t)e_first * cfg.GS))[grid_lane];
+    }
+
+    for (int e = e_first; e < cfg.n_envs; e += e_stride) {
+        // ---- zero the bitmap, park the record in LDS
         if (obs) {
-            const uint32_t* gsrc = (const uint32_t*)(p.grid + (size_t)e * cfg.GS);
-            for (int w = lane; w < cfg.GS / 4; w += WAVE) {
-                uint32_t cells = gsrc[w];
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            for (int q = lane; q < BQ; q += WAVE) ((u32x4_t*)bits)[q] = z;
+        }
+        if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- hot bits of every tile plane
+        if (has_cells) {
+            for (int w = lane; w < GW; w += WAVE) {
+                if (w >= WAVE) cells = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16 only
+                int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const int cell = w * 4 + b;
-                    if (cell < GG) {
-                        const uint32_t v = (cells >> (8 * b)) & 0xFFu;
-                        const int r = (int)fdiv((uint32_t)cell, cfg.div_g), c = cell - r * G;
-                        int fl;  // destination cell under the reversal (gridworld_ctf.py:1003-1007)
-                        if (cfg.flip_axis == -1) fl = GG - 1 - cell;
-                        else if (cfg.flip_axis == 0) fl = (G - 1 - r) * G + c;
-                        else if (cfg.flip_axis == 1) fl = r * G + (G - 1 - c);
-                        else fl = (G - 1 - c) * G + (G - 1 - r);
+                    const uint32_t v = (cells >> (8 * b)) & 0xFFu;
+                    if (v != 0 && cell < GG) {
+                        const int fl = flip_cell(cfg, cell, r, c);
 #pragma unroll
                         for (int slot = 0; slot < 4; slot++) {
-                            if (need & (1u << slot)) {
-                                const uint32_t code = (uint32_t)(cfg.chan_lut[slot >> 1] >> (4 * v)) & 15u;
-                                const int dst = (slot & 1) ? fl : cell;
-                                uint8_t* vs = views + slot * VS;
-                                vs[dst] = (uint8_t)code;
-                                vs[GG + dst] = (uint8_t)(code - 1u);
+                            if (slot_agents[slot]) {  // uniform
+                                const uint32_t code = (uint32_t)(pin64(cfg.chan_lut[slot >> 1]) >> (4 * v)) & 15u;
+                                if (code != CTF_TILE_NONE) {
+                                    const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
+                                    for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
+                                        const uint32_t bit = (uint32_t)(__ffs((int)m) - 1) * (uint32_t)cfg.CGG + q;
+                                        atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
+                                    }
+                                }
                             }
                         }
                     }
+                    if (++c == G) { c = 0; r++; }
                 }
             }
         }
-        __builtin_amdgcn_s_waitcnt(0);  // the wave's own LDS writes have landed before its reads below
-        __builtin_amdgcn_wave_barrier();
+        // ---- plane 0: the viewer's own position
         if (obs && lane < N) {
             const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
             const int r = ps[2 * lane], c = ps[2 * lane + 1];
-            const uint32_t rev = (reverse_mask >> lane) & 1u;
-            int cell = r * G + c;
-            if (rev) {
-                if (cfg.flip_axis == -1) cell = GG - 1 - cell;
-                else if (cfg.flip_axis == 0) cell = (G - 1 - r) * G + c;
-                else if (cfg.flip_axis == 1) cell = r * G + (G - 1 - c);
-                else cell = (G - 1 - c) * G + (G - 1 - r);
-            }
-            const uint32_t slot = (uint32_t)cfg.team[lane] * 2 + rev;
-            aginfo[lane] = ((uint32_t)(cfg.RS + 64 + slot * VS) << 16) | (uint32_t)cell;
+            const int cell = ((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c;
+            const uint32_t bit = (uint32_t)lane * (uint32_t)cfg.CGG + (uint32_t)cell;
+            atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
         }
-        __builtin_amdgcn_s_waitcnt(0);
+
+        // ---- metadata (gridworld_ctf.py:1027-1069).  A: the few distinct values, as f16 bits
+        if (meta && !(OBS_ABLATE & 8)) {
+            const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
+            if (lane < 36) {
+                double val = 0.0;
+                if (lane == 0) val = (double)misc[0] / (double)cfg.game_steps;
+                else if (lane < 3) val = (double)(misc[lane] + 1) / (double)(misc[3 - lane] + 1);  // viewer team lane-1
+                else if (lane >= 4 && lane < 4 + N) {
+                    // the quirk at :1039-1041: hp of the agent whose INDEX is type(j), over max hp of type(j), as uint8
+                    const int tv = cfg_type(cfg, lane - 4);
+                    double q = 0.0;
+                    if (tv < N) {
+                        const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
+                        q = __hiloint2double((int)hq[1], (int)hq[0]) / sel4(cfg.type_hp, tv);
+                    }
+                    val = (double)(uint8_t)(long long)q;
+                } else if (lane >= 20 && lane < 20 + N) val = (double)srec[cfg.off_flag + lane - 20];
+                mv[lane] = f64_to_f16(val);
+            }
+            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+            __builtin_amdgcn_wave_barrier();
+            // B: every element of the N x M block is one of those values
+            for (int idx = lane; idx < N * M; idx += WAVE) {
+                const int i = (int)fdiv((uint32_t)idx, cfg.div_m), k = idx - i * M;
+                const int team = cfg_team(cfg, i);
+                uint16_t hv = 0;
+                if (k == 0) hv = mv[0];
+                else if (k == 1) hv = mv[1 + team];
+                else if (k < 6) hv = (k - 2 == cfg_type(cfg, i)) ? (uint16_t)0x3C00u : (uint16_t)0u;
+                else {
+                    // rows 6,7: the agent itself; then own-team list minus self, then the opponents list (:1053-1067)
+                    int who = i;
+                    if (k >= 8) {
+                        const int pidx = (k - 8) >> 1;
+                        const int n_own = cfg_nopp(cfg, 1 - team), n_op = cfg_nopp(cfg, team);
+                        const int self_idx = (int)((pin64(cfg.self_idx_pack) >> (4 * i)) & 15u);
+                        const int n_mates = n_own - (self_idx < n_own ? 1 : 0);
+                        if (pidx < n_mates) who = cfg_opp(cfg, 1 - team, pidx + (pidx >= self_idx ? 1 : 0));
+                        else if (pidx - n_mates < n_op) who = cfg_opp(cfg, team, pidx - n_mates);
+                        else who = -1;
+                    }
+                    if (who >= 0) hv = mv[((k & 1) ? 20 : 4) + who];
+                }
+                mstage[idx] = hv;
+            }
+            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+            __builtin_amdgcn_wave_barrier();
+            // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
+            u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
+            for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)mstage)[q];
+        }
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the bitmap's atomic ORs have landed
         __builtin_amdgcn_wave_barrier();
 
-        // ---- metadata (gridworld_ctf.py:1027-1069): one lane per f16 element
-        if (meta) {
-            const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
-            const uint8_t* flag = srec + cfg.off_flag;
-            uint16_t* mdst = meta + (size_t)e * N * cfg.M;
-            for (int idx = lane; idx < N * cfg.M; idx += WAVE) {
-                const int i = (int)fdiv((uint32_t)idx, cfg.div_m), k = idx - i * cfg.M;
-                const int team = cfg.team[i];
-                double val = 0.0;
-                if (k == 0) val = (double)misc[0] / (double)cfg.game_steps;
-                else if (k == 1) val = (double)(misc[1 + team] + 1) / (double)(misc[1 + (1 - team)] + 1);
-                else if (k < 6) val = (k - 2 == cfg.type[i]) ? 1.0 : 0.0;
-                else {
-                    int who, which;
-                    if (k < 8) { who = i; which = k - 6; }
-                    else { who = cfg.meta_order[i][(k - 8) >> 1]; which = (k - 8) & 1; }
-                    if (who >= 0) {
-                        if (which) val = (double)flag[who];
-                        else {
-                            // the quirk at :1039-1041: hp of the agent whose INDEX is type(who), over max hp of type(who), as uint8
-                            const int tv = cfg.type[who];
-                            double q = 0.0;
-                            if (tv < N) {
-                                const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
-                                q = __hiloint2double((int)hq[1], (int)hq[0]) / cfg.type_hp[tv];
-                            }
-                            val = (double)(uint8_t)(long long)q;
-                        }
-                    }
-                }
-                mdst[idx] = f64_to_f16(val);
-            }
-        }
-
-        // ---- stream the observation block: u8 [N][C][G][G], 16 bytes per lane per iteration
+        // ---- stream the observation block: 16 bytes per lane per store.  Wave store instructions are
+        // aligned to 1 KiB of the flat output (k starts negative), so only an env's first and last
+        // instruction touch a partial line.
         if (obs) {
-            uint8_t* out = obs + (size_t)e * cfg.obs_bytes;
+            const size_t base = (size_t)e * cfg.obs_bytes;
+            uint8_t* out = obs + base;
+            const uint16_t* hb = (const uint16_t*)bits;
             const int nfull = cfg.obs_bytes >> 4;
             const int tail = cfg.obs_bytes & 15;
             const int nchunks = nfull + (tail ? 1 : 0);
-            for (int k = lane; k < nchunks; k += WAVE) {
-                const uint32_t o = (uint32_t)k << 4;
-                const uint32_t agent = fdiv(o, cfg.div_cgg);
-                const uint32_t rem = o - agent * (uint32_t)cfg.CGG;
-                const uint32_t c = fdiv(rem, cfg.div_gg);
-                const uint32_t cell0 = rem - c * (uint32_t)GG;
-                const uint32_t info = aginfo[agent];
-                const uint32_t addr = (info >> 16) + cell0;
-                const uint32_t* src = (const uint32_t*)(wl + (addr & ~3u));
-                const uint32_t sh = addr & 3u;
-                const uint32_t w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3], w4 = src[4];
-                const uint32_t cv = c * 0x01010101u;
-                uint32_t x[4];
-                x[0] = __builtin_amdgcn_alignbyte(w1, w0, sh) ^ cv;
-                x[1] = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ cv;
-                x[2] = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ cv;
-                x[3] = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ cv;
-                // byte == 0  ->  1 ; all bytes < 0x80 so the subtraction never borrows across bytes
-#pragma unroll
-                for (int j = 0; j < 4; j++) x[j] = ((0x80808080u - x[j]) >> 7) & 0x01010101u;
-                // plane 0 (own position) of this agent, or of the next agent when the chunk runs past plane C-1
-                int h = -1;
-                if (c == 0) h = (int)(info & 0xFFFFu) - (int)cell0;
-                else if (c == (uint32_t)(C - 1) && agent + 1 < (uint32_t)N) h = GG + (int)(aginfo[agent + 1] & 0xFFFFu) - (int)cell0;
-                if (h >= 0 && h < 16) {
-                    const uint32_t bit = 1u << ((h & 3) * 8);
-                    x[0] |= (h >> 2) == 0 ? bit : 0u;
-                    x[1] |= (h >> 2) == 1 ? bit : 0u;
-                    x[2] |= (h >> 2) == 2 ? bit : 0u;
-                    x[3] |= (h >> 2) == 3 ? bit : 0u;
+            const int k0 = (ALIGN >= 16) ? -(int)(((base + (uintptr_t)obs) >> 4) & 63) : 0;
+            uint32_t ablate_acc = 0;
+            const int niter = (nchunks - k0 + WAVE - 1) / WAVE;
+            const int e_next = min(e + e_stride, cfg.n_envs - 1);
+            uint32_t nrec = 0, ncells = 0;
+            for (int it = 0; it < niter; it++) {
+                if (it == 0) {  // next env's state: issued before this env's first store
+                    nrec = obs_prefetch_dword((const uint32_t*)(p.rec + (size_t)e_next * cfg.RS) + rec_lane);
+                    ncells = obs_prefetch_dword((const uint32_t*)(p.grid + (size_t)e_next * cfg.GS) + grid_lane);
                 }
+                if (it == OBS_PF_WAIT) OBS_PREFETCH_WAIT(nrec, ncells);
+                const int k = k0 + lane + it * WAVE;
+                if (k < 0 || k >= nchunks) continue;
+                const uint32_t o = (uint32_t)k << 4;
+                const uint32_t h = hb[k];
+                uint32_t x[4];
+                if (OBS_ABLATE & 1) { x[0] = x[1] = x[2] = x[3] = h; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x[j] = expand4(h, j);
+                }
+                if (OBS_ABLATE & 2) { ablate_acc ^= x[0] ^ x[1] ^ x[2] ^ x[3]; continue; }
                 if (k < nfull) {
                     if (ALIGN >= 4) {
                         typedef typename OutVec<(ALIGN >= 16 ? 16 : 4)>::type V;
-                        V v = {x[0], x[1], x[2], x[3]};
-                        __builtin_nontemporal_store(v, (V*)(out + o));
+                        const V v = {x[0], x[1], x[2], x[3]};
+                        *(V*)(out + o) = v;  // plain store: measured faster than nontemporal for this pattern
                     } else {
 #pragma unroll
                         for (int j = 0; j < 16; j++) out[o + j] = (uint8_t)(x[j >> 2] >> ((j & 3) * 8));
@@ -716,8 +885,14 @@ __global__ void __launch_bounds__(OBS_WAVES* WAVE) k_observe(DevCfg cfg, DevPtrs
                     for (int j = 0; j < tail; j++) out[o + j] = (uint8_t)(x[j >> 2] >> ((j & 3) * 8));
                 }
             }
+            if ((OBS_ABLATE & 2) && ablate_acc == 0x12345678u) out[lane] = 1;  // keeps the ablated work alive
+            if (niter <= OBS_PF_WAIT) OBS_PREFETCH_DRAIN(nrec, ncells);
+            recw = nrec;
+            cells = ncells;
+        } else if (e + e_stride < cfg.n_envs) {
+            recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
         }
-        __builtin_amdgcn_s_waitcnt(0);  // this env's LDS reads are done before the next env overwrites the slots
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // this env's LDS reads are done before the next env reuses the bitmap
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -775,11 +950,15 @@ extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const
 }
 extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask,
                                          int n_cus, hipStream_t st) {
-    const size_t sh = (size_t)OBS_WAVES * obs_wave_bytes(cfg.RS, cfg.GG);
-    int blocks = (cfg.n_envs + OBS_WAVES - 1) / OBS_WAVES;
-    const int cap = n_cus * 8;  // 8 blocks of 4 waves per CU = the 32-wave limit; grid-stride beyond that
+    // waves per block: 4 unless one env's bitmap is so large that 4 of them would crowd the CU's LDS
+    const int per_wave = obs_wave_bytes(cfg.RS, cfg.N, cfg.M, cfg.obs_bytes);
+    int wpb = 4;
+    while (wpb > 1 && wpb * per_wave > 40 * 1024) wpb >>= 1;
+    const size_t sh = (size_t)wpb * per_wave;
+    int blocks = (cfg.n_envs + wpb - 1) / wpb;
+    const int cap = n_cus * (32 / wpb);  // the CU's 32-wave limit; grid-stride beyond that
     if (blocks > cap) blocks = cap;
-    const dim3 grid(blocks), block(OBS_WAVES * WAVE);
+    const dim3 grid(blocks), block(wpb * WAVE);
     const uintptr_t a = (uintptr_t)obs;
     if ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0)
         hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);

@@ -1,0 +1,86 @@
+"""Multi-GPU layout of the path: envs are independent, so each rank (one process per GPU) owns a
+contiguous range of global env indices with its own handle and stream, and stepping / rendering needs
+no communication.  The only exchange is the rollout hand-off to the learner: an all-gather of the
+compact per-step tensors (rewards, done) over RCCL (backend "nccl" on ROCm), issued asynchronously so
+it overlaps the observation render.  The same code runs over gloo on CPU tensors in the tests.
+"""
+import os
+
+import numpy as np
+
+
+def world_from_env():
+    """(rank, local_rank, world_size) as torchrun exports them (1-process defaults otherwise)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def shard_range(n_global, rank, world):
+    """Contiguous split of n_global envs over `world` ranks; the first n_global % world ranks get one more."""
+    base, extra = divmod(int(n_global), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def env_seeds(run, lo, hi):
+    """per-env seeds s_py[e] = s_np[e] = 1_000_003 * run + e over GLOBAL env indices
+    (reduced modulo 2**32, np.random.seed's limit)."""
+    e = np.arange(lo, hi, dtype=np.uint64)
+    return (np.uint64(1_000_003) * np.uint64(run) + e) % np.uint64(2 ** 32)
+
+
+class RolloutGather:
+    """All-gather of the per-step compact rollout tensors (rewards [E, N] f32, done [E] u8) of every
+    shard, double-buffered so that the collective of step t may still be in flight while step t+1 runs."""
+
+    def __init__(self, rewards, done, world, group=None):
+        import torch
+
+        self.world, self.group = world, group
+        self.bufs = []
+        for _ in range(2):
+            self.bufs.append((
+                torch.empty((world * rewards.shape[0],) + tuple(rewards.shape[1:]), dtype=rewards.dtype, device=rewards.device),
+                torch.empty((world * done.shape[0],), dtype=done.dtype, device=done.device),
+            ))
+        self.pending = [None, None]
+        self.k = 0
+
+    def start(self, rewards, done):
+        """Enqueue the gather of this step's tensors (async); returns the slot it will land in."""
+        import torch.distributed as dist
+
+        slot = self.k & 1
+        self.wait(slot)
+        gr, gd = self.bufs[slot]
+        if self.world == 1:
+            gr.copy_(rewards, non_blocking=True)
+            gd.copy_(done, non_blocking=True)
+        else:
+            w1 = dist.all_gather_into_tensor(gr, rewards.contiguous(), group=self.group, async_op=True)
+            w2 = dist.all_gather_into_tensor(gd, done.contiguous(), group=self.group, async_op=True)
+            self.pending[slot] = (w1, w2)
+        self.k += 1
+        return slot
+
+    def wait(self, slot=None):
+        for s in ((0, 1) if slot is None else (slot,)):
+            if self.pending[s] is not None:
+                for w in self.pending[s]:
+                    w.wait()
+                self.pending[s] = None
+
+    def result(self, slot):
+        self.wait(slot)
+        return self.bufs[slot]
+
+
+def max_over_ranks(value, device, world):
+    """MAX over ranks of a python float (the timing rule of bench.py)."""
+    if world == 1:
+        return float(value)
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -84,7 +84,9 @@ def test_golden_trajectory(name):
     assert s["team_captures"] == case.meta["team_captures"]
     py, npw = vec.get_rng_state(0)
     assert np.array_equal(py, z["py_state"]) and np.array_equal(npw, z["np_state"])
-    assert vec.status() == 0
+    # envs 1 and 2 run other seeds; on the one-open-spawn-cell map they may legitimately find no respawn cell
+    allowed = abi.ST_NO_RESPAWN if name == "syn_edge_k1" else 0
+    assert vec.status() & ~allowed == 0
     vec.close()
 
 
@@ -132,7 +134,7 @@ def test_batch_matches_oracle(name, n_envs, steps, log_metrics):
             assert int(d[e]) == int(dn), ctx
             assert np.array_equal(o[e], ro), ctx
             assert np.array_equal(m[e], rm.view(np.uint16)), ctx
-    assert alive.sum() >= n_envs // 2
+    assert alive.sum() >= (n_envs // 8 if name == "syn_edge_k1" else n_envs // 2)  # that map starves respawns by design
     for e in range(0, n_envs, max(1, n_envs // 16)):
         if alive[e]:
             _state_equal(view_arrays(vec.get_state(e), case.n, case.g), view_arrays(refs[e].get_state(), case.n, case.g), f"{name} env {e} final")
