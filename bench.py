@@ -146,8 +146,9 @@ def main():
     elapsed = sh.max_over_ranks(elapsed, device, world)
     status = vec.status()
 
-    step_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    obs_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    step_all = np.array([e[0].elapsed_time(e[1]) for e in ev])
+    obs_all = np.array([e[1].elapsed_time(e[2]) for e in ev])
+    step_ms, obs_ms = float(step_all.mean()), float(obs_all.mean())
     if rank == 0:
         value = n_gpus * E * K / elapsed
         obs_bytes = observe_algorithmic_bytes(N, C, G) * E
@@ -189,6 +190,8 @@ def main():
                 "avg_launch_ms": obs_ms,
             },
             "kernels_ms": {"k_step": step_ms, "k_observe": obs_ms},
+            "kernels_ms_p10_p50_p90": {"k_step": [float(x) for x in np.percentile(step_all, [10, 50, 90])],
+                                       "k_observe": [float(x) for x in np.percentile(obs_all, [10, 50, 90])]},
             "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (step_ms * 1e-3) / 1e9,
             "device_status_bits": status,
         }

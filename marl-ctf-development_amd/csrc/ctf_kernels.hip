@@ -247,6 +247,15 @@ __device__ __forceinline__ void mtw_refill(MtWin& g) {
     }
     g.n = want; g.cur = 0;
 }
+// Lane-uniform top-up: every lane drops what it has not consumed and refills a full window.  Called where
+// all lanes of the wave are at the same program point (before a shuffle), so that the refill code runs
+// ONCE for the wave; without it the lanes' CPython streams (rejection sampling -> different positions)
+// exhaust their windows at different draws and the wave re-executes the refill for a few lanes each time
+// (measured: 23 refill executions per step instead of ~3).
+__device__ __forceinline__ void mtw_top_up(MtWin& g) {
+    mtw_flush(g);
+    mtw_refill(g);
+}
 __device__ __forceinline__ uint32_t mtw_next(MtWin& g) {
     if (g.cur == g.n) { mtw_flush(g); mtw_refill(g); }
     return mt_temper(g.win[g.cur++]);
@@ -349,6 +358,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, co
     // (:839-847) after.  One rolled loop holds both so that the RNG refill code exists once.
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {
+    mtw_top_up(py);
 #pragma unroll 1
     for (int i = N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
         const uint32_t j = py_randbelow(py, (uint32_t)i + 1u);
@@ -693,6 +703,9 @@ __device__ __forceinline__ uint32_t obs_prefetch_dword(const uint32_t* ptr) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
     return v;
 }
+#ifndef OBS_PREFETCH
+#define OBS_PREFETCH 1  // 0 = profiling comparison only (tools/ablate.sh)
+#endif
 #define OBS_PF_WAIT 10  // stream iteration at which the prefetched state is waited for ...
 // ... with vmcnt(8): the two prefetch loads are older than the >= OBS_PF_WAIT stores issued since
 #define OBS_PREFETCH_WAIT(a, b) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a), "+v"(b)::"memory")
@@ -856,11 +869,11 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
             const int e_next = min(e + e_stride, cfg.n_envs - 1);
             uint32_t nrec = 0, ncells = 0;
             for (int it = 0; it < niter; it++) {
-                if (it == 0) {  // next env's state: issued before this env's first store
+                if (OBS_PREFETCH && it == 0) {  // next env's state: issued before this env's first store
                     nrec = obs_prefetch_dword((const uint32_t*)(p.rec + (size_t)e_next * cfg.RS) + rec_lane);
                     ncells = obs_prefetch_dword((const uint32_t*)(p.grid + (size_t)e_next * cfg.GS) + grid_lane);
                 }
-                if (it == OBS_PF_WAIT) OBS_PREFETCH_WAIT(nrec, ncells);
+                if (OBS_PREFETCH && it == OBS_PF_WAIT) OBS_PREFETCH_WAIT(nrec, ncells);
                 const int k = k0 + lane + it * WAVE;
                 if (k < 0 || k >= nchunks) continue;
                 const uint32_t o = (uint32_t)k << 4;
@@ -886,9 +899,14 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
                 }
             }
             if ((OBS_ABLATE & 2) && ablate_acc == 0x12345678u) out[lane] = 1;  // keeps the ablated work alive
-            if (niter <= OBS_PF_WAIT) OBS_PREFETCH_DRAIN(nrec, ncells);
-            recw = nrec;
-            cells = ncells;
+            if (OBS_PREFETCH) {
+                if (niter <= OBS_PF_WAIT) OBS_PREFETCH_DRAIN(nrec, ncells);
+                recw = nrec;
+                cells = ncells;
+            } else if (e + e_stride < cfg.n_envs) {
+                recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
+                cells = ((const uint32_t*)(p.grid + (size_t)(e + e_stride) * cfg.GS))[grid_lane];
+            }
         } else if (e + e_stride < cfg.n_envs) {
             recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
         }
