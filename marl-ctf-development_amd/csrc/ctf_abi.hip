@@ -128,8 +128,13 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
         !make_fastdiv((uint32_t)N, (uint32_t)(64 * N) + 64, &d->div_n) ||
         !make_fastdiv((uint32_t)(d->GS / 16), (uint32_t)(64 * d->GS / 16) + 64, &d->div_gq) ||
         !make_fastdiv((uint32_t)(d->RS / 16), (uint32_t)(64 * d->RS / 16) + 64, &d->div_rq) ||
-        !make_fastdiv((uint32_t)(CTF_N_METRICS * N), (uint32_t)(64 * CTF_N_METRICS * N) + 64, &d->div_mn))
+        !make_fastdiv((uint32_t)(CTF_N_METRICS * N), (uint32_t)(64 * CTF_N_METRICS * N) + 64, &d->div_mn) ||
+        !make_fastdiv((uint32_t)((CTF_N_METRICS * N + 3) / 4), (uint32_t)(64 * ((CTF_N_METRICS * N + 3) / 4)) + 64, &d->div_mw))
         return fail(CTF_E_INVALID, "internal: reciprocal division not exact for these dimensions");
+    if (const char* ov = getenv("CTF_STEP_W")) {
+        const int w = atoi(ov);
+        if (w == 1 || w == 2 || w == 4 || w == 8) d->step_lanes_override = w;
+    }
     d->heal = c->heal_per_step; d->tag_p = c->tag_probability; d->guard_mult = c->guardian_damage_multiplier;
     d->vault_cost = c->vault_hp_cost; d->vault_min = c->vault_min_hp;
     d->r_capture = c->reward_capture; d->r_step = c->reward_step; d->r_tag = c->reward_tag;

@@ -32,7 +32,8 @@ struct DevCfg {
     int32_t CGG, obs_bytes;         // C*G*G, N*C*G*G
     int32_t off_pos, off_flag, off_perm, off_inv, off_misc;  // record offsets (hp is at 0)
     int32_t default_reverse;        // bit i = (team(i) == 1)
-    FastDiv div_cgg, div_gg, div_g, div_m, div_n, div_gq, div_rq, div_mn;
+    FastDiv div_cgg, div_gg, div_g, div_m, div_n, div_gq, div_rq, div_mn, div_mw;
+    int32_t step_lanes_override;    // 0 = automatic; set from CTF_STEP_W for profiling
     double heal, tag_p, guard_mult, vault_cost, vault_min;
     double r_capture, r_step, r_tag, win_scalar, loss_scalar, punish;
     double type_hp[4], type_damage[4];

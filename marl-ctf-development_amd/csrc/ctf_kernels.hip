@@ -178,12 +178,23 @@ __device__ __forceinline__ double sel4(const double* t, int k) {
 #define TSEL(arr, team, k) ((team) ? pin((int)(arr)[1][k]) : pin((int)(arr)[0][k]))
 
 // ------------------------------------------------------------------------------------------------
-// step — one lane per env, 64 envs per 64-thread block, state staged through LDS
+// step — W lanes per env (W = 1, 2, 4 or 8 >= opponents per team), 64 / W envs per 64-thread block
 // ------------------------------------------------------------------------------------------------
+// The per-agent loop of GridworldCtf.step is inherently sequential (later agents see earlier agents' moves, tags and
+// respawns), so parallelism is across envs — but one lane per env leaves one wave per SIMD and a kernel bound by the
+// dependent LDS / VALU chain.  Here the W lanes of a group run the env's control flow redundantly (state reads are LDS
+// broadcasts; state WRITES are done by sub-lane 0 only) and split the work that is parallel inside an agent's turn:
+//   - tagging: sub-lane q draws the np.random.rand() of opponent q from its own two window words and tests range;
+//     __ballot finds the first hit, which is applied (possibly respawning, which consumes extra words) before the
+//     remaining opponents are re-evaluated from the shifted stream position — exactly the reference's draw order;
+//   - adjacency / zone metrics, healing, rewards, visitation: one agent per sub-lane;
+//   - MT window refills and write-backs: one word per sub-lane per pass.
+// 64 / W envs per wave means W times more waves (4 per SIMD for the arena) to hide the latency chain.
+//
 // LDS slot of one env (bytes):
 //   [grid GS][rec RS][actions 16][py window 64][np window 64][metric deltas u8 13*N (METRICS)]
-// The slot stride in dwords is odd so that the 64 lanes' same-offset accesses fall in distinct banks.
-#define WCAP 16  // MT words per refill of a stream's window
+// The slot stride in dwords is odd so that different groups' same-offset accesses fall in distinct banks.
+#define WCAP 16  // MT words per window (>= 2 * max opponents per team)
 
 __host__ __device__ inline int step_slot_bytes(int GS, int RS, int N, bool metrics) {
     int b = GS + RS + 16 + 2 * WCAP * 4 + (metrics ? ((CTF_N_METRICS * N + 3) & ~3) : 0);
@@ -191,13 +202,14 @@ __host__ __device__ inline int step_slot_bytes(int GS, int RS, int N, bool metri
     return b;
 }
 
-// One MT19937 stream of one env: state words in HBM, a small window of the next words in LDS.
-// Lazy in-place regeneration (see Mt above); a refill issues all its loads back to back, so a step pays
-// one exposed memory latency per WCAP words instead of one per word.
+// One MT19937 stream of one env: state words in HBM, a WCAP-word window of the next words in LDS (untempered, already
+// regenerated).  All fields are replicated in the registers of the group's W lanes and updated identically.
+// Lazy in-place regeneration (see above); a window may span the end of a block: word idx >= 624 is word idx-624 of
+// the next block and is always regenerated.
 struct MtWin {
     uint32_t* a;    // 624 state words (global)
-    uint32_t* win;  // WCAP untempered words, already regenerated (LDS)
-    uint32_t pos;   // stream position of win[0]
+    uint32_t* win;  // WCAP words (LDS)
+    uint32_t pos;   // stream position of win[0], 0..624
     uint32_t lazy;
     uint32_t n, cur;
 };
@@ -209,106 +221,103 @@ __device__ __forceinline__ MtWin mtw_open(uint32_t* base, uint32_t* win, uint32_
     g.n = 0; g.cur = 0;
     return g;
 }
-// write the consumed, regenerated words back and advance; unconsumed window words are simply dropped
-// (they are recomputed from unchanged state words on the next refill)
-__device__ __forceinline__ void mtw_flush(MtWin& g) {
-    if (g.lazy)
-        for (uint32_t j = 0; j < g.cur; j++) g.a[g.pos + j] = g.win[j];
+// write the consumed, regenerated words back (one word per sub-lane per pass) and advance; unconsumed window words
+// are simply dropped — they are recomputed from unchanged state words by the next refill
+template <int W>
+__device__ __forceinline__ void mtw_flush(MtWin& g, int j) {
+    for (uint32_t jj = (uint32_t)j; jj < g.cur; jj += W) {
+        const uint32_t idx = g.pos + jj;
+        const bool wrapped = idx >= CTF_MT_N;
+        if (g.lazy | (uint32_t)wrapped) g.a[wrapped ? idx - CTF_MT_N : idx] = g.win[jj];
+    }
     g.pos += g.cur;
+    if (g.pos > CTF_MT_N) { g.pos -= CTF_MT_N; g.lazy = 1; }
     g.n = 0; g.cur = 0;
 }
-__device__ __forceinline__ uint32_t mtw_close(MtWin& g) {
-    mtw_flush(g);
-    return g.pos | (g.lazy ? CTF_LAZY_BIT : 0u);
-}
-__device__ __forceinline__ void mtw_refill(MtWin& g) {
-    if (g.pos >= CTF_MT_N) { g.pos = 0; g.lazy = 1; }
-    const uint32_t want = min((uint32_t)WCAP, (uint32_t)CTF_MT_N - g.pos);
-    uint32_t x[WCAP + 1], m[WCAP];
+template <int W>
+__device__ __forceinline__ void mtw_refill(MtWin& g, int j) {
+    constexpr int T = WCAP / W;
+    uint32_t x0[T], x1[T], m[T];
+    bool lz[T];
 #pragma unroll
-    for (int j = 0; j <= WCAP; j++) {
-        const uint32_t i = g.pos + j;
-        x[j] = ((uint32_t)j <= want) ? g.a[i == CTF_MT_N ? 0u : i] : 0u;
+    for (int t = 0; t < T; t++) {  // all loads first: one exposed memory latency per refill
+        const uint32_t idx = g.pos + (uint32_t)(j + t * W);
+        const bool wrapped = idx >= CTF_MT_N;
+        const uint32_t i = wrapped ? idx - CTF_MT_N : idx;
+        lz[t] = (g.lazy | (uint32_t)wrapped) != 0;
+        x0[t] = g.a[i];
+        x1[t] = g.a[i + 1 == CTF_MT_N ? 0u : i + 1];
+        m[t] = g.a[i + 397 >= CTF_MT_N ? i + 397 - CTF_MT_N : i + 397];
     }
-    if (g.lazy) {
 #pragma unroll
-        for (int j = 0; j < WCAP; j++) {
-            const uint32_t i = g.pos + j;
-            m[j] = ((uint32_t)j < want) ? g.a[i + 397 >= CTF_MT_N ? i + 397 - CTF_MT_N : i + 397] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < WCAP; j++) {
-            const uint32_t y = (x[j] & 0x80000000u) | (x[j + 1] & 0x7fffffffu);
-            g.win[j] = m[j] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < WCAP; j++) g.win[j] = x[j];
+    for (int t = 0; t < T; t++) {
+        const uint32_t y = (x0[t] & 0x80000000u) | (x1[t] & 0x7fffffffu);
+        const uint32_t v = m[t] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        g.win[j + t * W] = lz[t] ? v : x0[t];
     }
-    g.n = want; g.cur = 0;
+    g.n = WCAP; g.cur = 0;
 }
-// Lane-uniform top-up: every lane drops what it has not consumed and refills a full window.  Called where
-// all lanes of the wave are at the same program point (before a shuffle), so that the refill code runs
-// ONCE for the wave; without it the lanes' CPython streams (rejection sampling -> different positions)
-// exhaust their windows at different draws and the wave re-executes the refill for a few lanes each time
-// (measured: 23 refill executions per step instead of ~3).
-__device__ __forceinline__ void mtw_top_up(MtWin& g) {
-    mtw_flush(g);
-    mtw_refill(g);
+// make sure `need` (<= WCAP) words are in the window; group-uniform, so the W lanes refill together
+template <int W>
+__device__ __forceinline__ void mtw_ensure(MtWin& g, int j, uint32_t need) {
+    if (g.n - g.cur < need) { mtw_flush<W>(g, j); mtw_refill<W>(g, j); }
 }
-__device__ __forceinline__ uint32_t mtw_next(MtWin& g) {
-    if (g.cur == g.n) { mtw_flush(g); mtw_refill(g); }
+template <int W>
+__device__ __forceinline__ uint32_t mtw_next(MtWin& g, int j) {
+    mtw_ensure<W>(g, j, 1);
     return mt_temper(g.win[g.cur++]);
 }
-// (each helper holds exactly ONE inlined copy of the refill code: keep the loops rolled)
-__device__ __forceinline__ uint32_t py_randbelow(MtWin& g, uint32_t n) {
-    const uint32_t sh = (uint32_t)__clz((int)n);  // 32 - n.bit_length()
+// CPython random._randbelow_with_getrandbits(n): k = n.bit_length(); draw k bits until < n
+template <int W>
+__device__ __forceinline__ uint32_t py_randbelow(MtWin& g, int j, uint32_t n) {
+    const uint32_t sh = (uint32_t)__clz((int)n);
     uint32_t r;
-    do { r = mtw_next(g) >> sh; } while (r >= n);
+    do { r = mtw_next<W>(g, j) >> sh; } while (r >= n);
     return r;
 }
-__device__ __forceinline__ double np_rand(MtWin& g) {
-    uint32_t a = 0, b = 0;
-#pragma unroll 1
-    for (int t = 0; t < 2; t++) {
-        const uint32_t v = mtw_next(g);
-        if (t == 0) a = v >> 5;
-        else b = v >> 6;
-    }
-    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
-}
-__device__ __forceinline__ uint32_t np_randint(MtWin& g, uint32_t k) {
+// NumPy legacy randint(k), k >= 1: masked rejection on one 32-bit word; k == 1 draws nothing
+template <int W>
+__device__ __forceinline__ uint32_t np_randint(MtWin& g, int j, uint32_t k) {
     const uint32_t rng = k - 1;
-    if (rng == 0) return 0;  // randint(1) draws nothing
+    if (rng == 0) return 0;
     const uint32_t mask = 0xFFFFFFFFu >> __clz((int)rng);
     uint32_t v;
-    do { v = mtw_next(g) & mask; } while (v > rng);
+    do { v = mtw_next<W>(g, j) & mask; } while (v > rng);
     return v;
 }
 
+template <int W>
 struct StepCtx {
-    uint8_t* sg;  // grid  (LDS)
-    uint8_t* sr;  // record (LDS)
-    uint8_t* sm;  // metric deltas of this step (LDS) or nullptr
+    uint8_t* sg;   // grid  (LDS)
+    uint8_t* sr;   // record (LDS)
+    uint8_t* sm;   // metric deltas of this step (LDS) or nullptr
+    int j;         // sub-lane within the env's group
+    int gshift;    // first lane of the group
+    bool lead;     // j == 0: performs the state writes
+    __device__ __forceinline__ uint32_t ballot(bool p) const {
+        return (uint32_t)(__ballot(p) >> gshift) & ((1u << W) - 1u);
+    }
 };
 
-__device__ __forceinline__ double ld_hp(const StepCtx& s, int a) {
+template <int W>
+__device__ __forceinline__ double ld_hp(const StepCtx<W>& s, int a) {
     const uint32_t* q = (const uint32_t*)(s.sr + 8 * a);
     return __hiloint2double((int)q[1], (int)q[0]);
 }
-__device__ __forceinline__ void st_hp(const StepCtx& s, int a, double v) {
+template <int W>
+__device__ __forceinline__ void st_hp(const StepCtx<W>& s, int a, double v) {
     uint32_t* q = (uint32_t*)(s.sr + 8 * a);
     q[0] = (uint32_t)__double2loint(v);
     q[1] = (uint32_t)__double2hiint(v);
 }
-
-template <bool METRICS>
-__device__ __forceinline__ void metric_add(const DevCfg& cfg, const StepCtx& s, int m, int a, int v) {
-    if (METRICS) s.sm[m * cfg.N + a] += (uint8_t)v;  // per-step deltas stay far below 256
+template <bool METRICS, int W>
+__device__ __forceinline__ void metric_add(const DevCfg& cfg, const StepCtx<W>& s, int m, int a, int v) {
+    if (METRICS && s.lead) s.sm[m * cfg.N + a] += (uint8_t)v;  // per-step deltas stay far below 256
 }
 
-// respawn, gridworld_ctf.py:761-794
-__device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx& s, MtWin& np_, int o, uint32_t& status) {
+// respawn, gridworld_ctf.py:761-794 (all lanes of the group compute; sub-lane 0 writes)
+template <int W>
+__device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx<W>& s, MtWin& np_, int o, uint32_t& flagm, uint32_t& status) {
     const int G = cfg.G, team = cfg_team(cfg, o), type = cfg_type(cfg, o);
     const int x = TSEL(cfg.spawn_pos, team, 0), y = TSEL(cfg.spawn_pos, team, 1);
     const int r0 = x - 1 > 0 ? x - 1 : 0, c0 = y - 1 > 0 ? y - 1 : 0;
@@ -320,7 +329,7 @@ __device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx& s, MtW
         for (int c = c0; c < c1; c++)
             if (s.sg[r * G + c] == 0) { open |= 1u << ((r - r0) * 3 + (c - c0)); k++; }
     if (k == 0) { status |= CTF_ST_NO_RESPAWN; return; }
-    const uint32_t rnd = np_randint(np_, (uint32_t)k);
+    const uint32_t rnd = np_randint<W>(np_, s.j, (uint32_t)k);
     uint32_t bits = open;
     for (uint32_t t = 0; t < rnd; t++) bits &= bits - 1;  // drop the rnd lowest candidates
     const int sel = __ffs((int)bits) - 1;
@@ -328,159 +337,209 @@ __device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx& s, MtW
     if (nr < 0 || nc < 0) { status |= CTF_ST_SPAWN_EDGE; nr = nr < 0 ? nr + G : nr; nc = nc < 0 ? nc + G : nc; }
     int8_t* ps = (int8_t*)(s.sr + cfg.off_pos);
     const int orow = ps[2 * o], ocol = ps[2 * o + 1];
-    s.sg[orow * G + ocol] = 0;
-    s.sg[nr * G + nc] = (uint8_t)(4 + type + 4 * team);
-    ps[2 * o] = (int8_t)nr;
-    ps[2 * o + 1] = (int8_t)nc;
-    st_hp(s, o, sel4(cfg.type_hp, type));
-    if (s.sr[cfg.off_flag + o]) {
-        s.sr[cfg.off_flag + o] = 0;
-        if (cfg.drop_flag) s.sg[orow * G + ocol] = (uint8_t)(12 + (1 - team));
-        else s.sg[TSEL(cfg.flag_pos, 1 - team, 0) * G + TSEL(cfg.flag_pos, 1 - team, 1)] = (uint8_t)(12 + (1 - team));
+    const bool carrying = (flagm >> o) & 1u;
+    if (s.lead) {
+        s.sg[orow * G + ocol] = 0;
+        s.sg[nr * G + nc] = (uint8_t)(4 + type + 4 * team);
+        ps[2 * o] = (int8_t)nr;
+        ps[2 * o + 1] = (int8_t)nc;
+        st_hp(s, o, sel4(cfg.type_hp, type));
+        if (carrying) {
+            if (cfg.drop_flag) s.sg[orow * G + ocol] = (uint8_t)(12 + (1 - team));
+            else s.sg[TSEL(cfg.flag_pos, 1 - team, 0) * G + TSEL(cfg.flag_pos, 1 - team, 1)] = (uint8_t)(12 + (1 - team));
+        }
     }
+    flagm &= ~(1u << o);
 }
 
-// The body of GridworldCtf.step for ONE env whose state sits in LDS.  Returns rewards through `rw`.
-template <bool METRICS>
-__device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, const int8_t* act, MtWin& py, MtWin& np_,
-                                         uint32_t& status, double* rw /*[CTF_MAX_AGENTS], statically indexed*/) {
-    const int N = cfg.N, G = cfg.G;
+// GridworldCtf.step for ONE env (state in LDS), executed by the W lanes of its group.
+template <bool METRICS, int W>
+__device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, const StepCtx<W>& s, const int8_t* act, MtWin& py,
+                                         MtWin& np_, uint32_t& status, int e, float* __restrict__ rw32, double* __restrict__ rw64,
+                                         uint8_t* __restrict__ done_out) {
+    const int N = cfg.N, G = cfg.G, j = s.j;
     int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
     int8_t* ps = (int8_t*)(s.sr + cfg.off_pos);
-    uint8_t* flag = s.sr + cfg.off_flag;
-    uint8_t* perm = s.sr + cfg.off_perm;
     int16_t* inv = (int16_t*)(s.sr + cfg.off_inv);
 
-    misc[0] += 1;  // env_step_count
+    // replicated register copies of the small per-env state: step, captures, has_flag bits, _arr as nibbles
+    const int step = misc[0] + 1;
+    int caps[2] = {misc[1], misc[2]};
+    uint32_t flagm = 0;
+    uint64_t perm = 0;
+#pragma unroll
+    for (int i = 0; i < CTF_MAX_AGENTS; i++) {
+        if (i < N) {
+            flagm |= (uint32_t)(s.sr[cfg.off_flag + i] & 1u) << i;
+            perm |= (uint64_t)(s.sr[cfg.off_perm + i] & 15u) << (4 * i);
+        }
+    }
     uint32_t cap_mask = 0, resp_mask = 0, cap_team = 0;
 
-    // Two shuffles per step: dice_roll (:734-742) before the agents act and the one inside heal_agents
-    // (:839-847) after.  One rolled loop holds both so that the RNG refill code exists once.
+    // Two shuffles per step: dice_roll (:734-742) before the agents act and the one inside heal_agents (:839-847)
+    // after.  One rolled loop holds both so that the RNG refill code exists once.
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {
-    mtw_top_up(py);
+        // top the CPython window up while the whole wave is at the same point (rejection sampling lets the groups'
+        // stream positions diverge; refilling on demand would re-run the refill per group)
+        mtw_flush<W>(py, j);
+        mtw_refill<W>(py, j);
 #pragma unroll 1
-    for (int i = N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
-        const uint32_t j = py_randbelow(py, (uint32_t)i + 1u);
-        const uint8_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
-    }
-    if (phase == 1) break;
+        for (int i = N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
+            const uint32_t r = py_randbelow<W>(py, j, (uint32_t)i + 1u);
+            const uint64_t vi = (perm >> (4 * i)) & 15u, vr = (perm >> (4 * r)) & 15u;
+            perm = (perm & ~((uint64_t)15u << (4 * i)) & ~((uint64_t)15u << (4 * r))) | (vr << (4 * i)) | (vi << (4 * r));
+        }
+        if (phase == 1) break;
 
-    for (int k = 0; k < N; k++) {
-        const int a = perm[k];
-        const int type = cfg_type(cfg, a), team = cfg_team(cfg, a);
-        int action = act[a];
-        if (action < 0 || action >= CTF_N_ACTIONS) { status |= CTF_ST_BAD_ACTION; action = 4; }
+#pragma unroll 1
+        for (int k = 0; k < N; k++) {
+            const int a = (int)((perm >> (4 * k)) & 15u);
+            const int type = cfg_type(cfg, a), team = cfg_team(cfg, a);
+            int action = act[a];
+            if (action < 0 || action >= CTF_N_ACTIONS) { status |= CTF_ST_BAD_ACTION; action = 4; }
 
-        // ---- act (:700-732); ACTION_DELTAS (:100-145): vaulter jumps 2, miner acts at distance 1 on 5..8
-        const int base = action <= 4 ? action : action - 5;
-        const int scale = action <= 4 ? 1 : (type == 2 ? 2 : (type == 3 ? 1 : 0));
-        const int dr = (base == 0 ? -1 : (base == 1 ? 1 : 0)) * scale;
-        const int dc = (base == 2 ? 1 : (base == 3 ? -1 : 0)) * scale;
-        int pr = ps[2 * a], pc = ps[2 * a + 1];
-        const int nr = pr + dr, nc = pc + dc;
-        if (nr >= 0 && nr < G && nc >= 0 && nc < G) {
-            const int cell = s.sg[nr * G + nc];
-            if (cell == 0 && (action <= 3 || (action >= 5 && type == 2 && (ld_hp(s, a) - cfg.vault_cost) > cfg.vault_min))) {
-                // movement_handler (:569-612)
-                s.sg[pr * G + pc] = 0;
-                s.sg[nr * G + nc] = (uint8_t)(4 + type + 4 * team);
-                pr = nr; pc = nc;
-                ps[2 * a] = (int8_t)nr;
-                ps[2 * a + 1] = (int8_t)nc;
-                const int ofr = TSEL(cfg.flag_pos, 1 - team, 0), ofc = TSEL(cfg.flag_pos, 1 - team, 1);
-                const int hfr = TSEL(cfg.flag_pos, team, 0), hfc = TSEL(cfg.flag_pos, team, 1);
-                if (cheb(nr, nc, ofr, ofc) <= 1 && s.sg[ofr * G + ofc] == 12 + (1 - team)) {  // pickup: flag cell -> BLOCK
-                    flag[a] = 1;
-                    s.sg[ofr * G + ofc] = 1;
-                    metric_add<METRICS>(cfg, s, CTF_M_FLAG_PICKUPS, a, 1);
-                }
-                if (cheb(nr, nc, hfr, hfc) <= 1 && flag[a] == 1) {  // capture
-                    if (!cfg.home_flag_capture || s.sg[hfr * G + hfc] == 12 + team) {
-                        flag[a] = 0;
-                        s.sg[ofr * G + ofc] = (uint8_t)(12 + (1 - team));
-                        misc[1 + team] += 1;
-                        metric_add<METRICS>(cfg, s, CTF_M_FLAG_CAPTURES, a, 1);
-                        cap_mask |= 1u << a;
-                        cap_team |= 1u << team;
+            // ---- act (:700-732); ACTION_DELTAS (:100-145): vaulter jumps 2, miner acts at distance 1 on 5..8
+            const int base = action <= 4 ? action : action - 5;
+            const int scale = action <= 4 ? 1 : (type == 2 ? 2 : (type == 3 ? 1 : 0));
+            const int dr = (base == 0 ? -1 : (base == 1 ? 1 : 0)) * scale;
+            const int dc = (base == 2 ? 1 : (base == 3 ? -1 : 0)) * scale;
+            int pr = ps[2 * a], pc = ps[2 * a + 1];
+            const int nr = pr + dr, nc = pc + dc;
+            if (nr >= 0 && nr < G && nc >= 0 && nc < G) {
+                const int cell = s.sg[nr * G + nc];
+                if (cell == 0 && (action <= 3 || (action >= 5 && type == 2 && (ld_hp(s, a) - cfg.vault_cost) > cfg.vault_min))) {
+                    // movement_handler (:569-612)
+                    const int ofr = TSEL(cfg.flag_pos, 1 - team, 0), ofc = TSEL(cfg.flag_pos, 1 - team, 1);
+                    const int hfr = TSEL(cfg.flag_pos, team, 0), hfc = TSEL(cfg.flag_pos, team, 1);
+                    const int opp_flag_cell = s.sg[ofr * G + ofc], home_flag_cell = s.sg[hfr * G + hfc];  // neither is the moved-from / moved-to cell
+                    if (s.lead) {
+                        s.sg[pr * G + pc] = 0;
+                        s.sg[nr * G + nc] = (uint8_t)(4 + type + 4 * team);
+                        ps[2 * a] = (int8_t)nr;
+                        ps[2 * a + 1] = (int8_t)nc;
+                    }
+                    pr = nr; pc = nc;
+                    if (cheb(nr, nc, ofr, ofc) <= 1 && opp_flag_cell == 12 + (1 - team)) {  // pickup: flag cell -> BLOCK
+                        flagm |= 1u << a;
+                        if (s.lead) s.sg[ofr * G + ofc] = 1;
+                        metric_add<METRICS>(cfg, s, CTF_M_FLAG_PICKUPS, a, 1);
+                    }
+                    if (cheb(nr, nc, hfr, hfc) <= 1 && ((flagm >> a) & 1u)) {  // capture
+                        if (!cfg.home_flag_capture || home_flag_cell == 12 + team) {
+                            flagm &= ~(1u << a);
+                            if (s.lead) s.sg[ofr * G + ofc] = (uint8_t)(12 + (1 - team));
+                            caps[0] += team == 0;
+                            caps[1] += team == 1;
+                            metric_add<METRICS>(cfg, s, CTF_M_FLAG_CAPTURES, a, 1);
+                            cap_mask |= 1u << a;
+                            cap_team |= 1u << team;
+                        }
+                    }
+                    if (action >= 5 && type == 2) {  // update_vaulter_hp
+                        const double h = ld_hp(s, a) - cfg.vault_cost;
+                        if (s.lead) st_hp(s, a, h);
+                    }
+                } else if (action >= 5 && type == 3 && inv[a] > 0 && cell == 0 &&
+                           cheb(nr, nc, TSEL(cfg.spawn_pos, team, 0), TSEL(cfg.spawn_pos, team, 1)) > 1 &&
+                           cheb(nr, nc, TSEL(cfg.spawn_pos, 1 - team, 0), TSEL(cfg.spawn_pos, 1 - team, 1)) > 1) {
+                    if (s.lead) {
+                        s.sg[nr * G + nc] = 2;  // add_block (:614-634)
+                        inv[a] -= 1;
+                    }
+                    if (METRICS) {
+                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID, a, 1);
+                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OWN_FLAG, a,
+                                            cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)));
+                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OPP_FLAG, a,
+                                            cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)));
+                    }
+                } else if (action < 5 && type == 3 && (cell == 2 || cell == 3)) {
+                    if (cell == 2) {
+                        if (s.lead) s.sg[nr * G + nc] = 3;  // mine_block (:677-690)
+                    } else {
+                        if (s.lead) {
+                            s.sg[nr * G + nc] = 0;
+                            if (inv[a] < 1000) inv[a] += 1;
+                        }
+                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_MINED, a, 1);
                     }
                 }
-                if (action >= 5 && type == 2) st_hp(s, a, ld_hp(s, a) - cfg.vault_cost);  // update_vaulter_hp
-            } else if (action >= 5 && type == 3 && inv[a] > 0 && cell == 0 &&
-                       cheb(nr, nc, TSEL(cfg.spawn_pos, team, 0), TSEL(cfg.spawn_pos, team, 1)) > 1 &&
-                       cheb(nr, nc, TSEL(cfg.spawn_pos, 1 - team, 0), TSEL(cfg.spawn_pos, 1 - team, 1)) > 1) {
-                s.sg[nr * G + nc] = 2;  // add_block (:614-634)
-                inv[a] -= 1;
-                if (METRICS) {
-                    metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID, a, 1);
-                    metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OWN_FLAG, a,
-                                        cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)));
-                    metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OPP_FLAG, a,
-                                        cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)));
-                }
-            } else if (action < 5 && type == 3 && (cell == 2 || cell == 3)) {
-                if (cell == 2) {
-                    s.sg[nr * G + nc] = 3;  // mine_block (:677-690)
-                } else {
-                    s.sg[nr * G + nc] = 0;
-                    if (inv[a] < 1000) inv[a] += 1;
-                    metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_MINED, a, 1);
-                }
             }
-        }
 
-        // ---- tagging_logic (:796-837)
-        const double dmg = sel4(cfg.type_damage, type);
-        if (dmg > 0) {
-            double mult = 1.0;
-            if (type == 1 && cheb(pr, pc, TSEL(cfg.flag_pos, team, 0), TSEL(cfg.flag_pos, team, 1)) <= 3) mult = cfg.guard_mult;
-            const double hit = dmg * mult;
-            const int no = cfg_nopp(cfg, team);
-            for (int q = 0; q < no; q++) {
-                const int o = cfg_opp(cfg, team, q);
-                const double u = np_rand(np_);  // drawn first, unconditionally
-                if (u < cfg.tag_p && cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1) {
+            // ---- tagging_logic (:796-837): sub-lane q evaluates opponent q0+q; hits are applied in opponent order
+            const double dmg = sel4(cfg.type_damage, type);
+            if (dmg > 0) {
+                double mult = 1.0;
+                if (type == 1 && cheb(pr, pc, TSEL(cfg.flag_pos, team, 0), TSEL(cfg.flag_pos, team, 1)) <= 3) mult = cfg.guard_mult;
+                const double hit = dmg * mult;
+                const int no = cfg_nopp(cfg, team);
+                int q0 = 0;
+#pragma unroll 1
+                while (q0 < no) {
+                    const int left = no - q0;
+                    const int cnt = left < W ? left : W;  // opponents evaluated in this pass
+                    mtw_ensure<W>(np_, j, (uint32_t)(2 * cnt));
+                    bool is_hit = false;
+                    if (j < cnt) {
+                        const int o = cfg_opp(cfg, team, q0 + j);
+                        const uint32_t wa = mt_temper(np_.win[np_.cur + 2 * j]) >> 5, wb = mt_temper(np_.win[np_.cur + 2 * j + 1]) >> 6;
+                        const double u = ((double)wa * 67108864.0 + (double)wb) * (1.0 / 9007199254740992.0);  // np.random.rand()
+                        is_hit = (u < cfg.tag_p) && cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1;
+                    }
+                    const uint32_t hits = s.ballot(is_hit);
+                    if (hits == 0) {  // nobody tagged: all cnt doubles consumed
+                        np_.cur += 2 * cnt;
+                        q0 += cnt;
+                        continue;
+                    }
+                    const int first = __ffs((int)hits) - 1;
+                    np_.cur += 2 * (first + 1);  // doubles up to and including the tagged opponent's
+                    const int o = cfg_opp(cfg, team, q0 + first);
                     const double h = ld_hp(s, o) - hit;
-                    st_hp(s, o, h);
+                    if (s.lead) st_hp(s, o, h);
                     metric_add<METRICS>(cfg, s, CTF_M_TAG_COUNT, a, 1);
                     if (h <= 0) {
-                        if (flag[o] == 1) metric_add<METRICS>(cfg, s, CTF_M_FLAG_DISPOSSESSIONS, a, 1);
-                        respawn(cfg, s, np_, o, status);
+                        if ((flagm >> o) & 1u) metric_add<METRICS>(cfg, s, CTF_M_FLAG_DISPOSSESSIONS, a, 1);
+                        respawn<W>(cfg, s, np_, o, flagm, status);  // may draw randint words right here
                         resp_mask |= 1u << a;
                         metric_add<METRICS>(cfg, s, CTF_M_RESPAWN_TAG_COUNT, a, 1);
                     }
+                    q0 += first + 1;
                 }
             }
-        }
 
-        // ---- metric-only section (:879-902)
-        if (METRICS) {
-            if (cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)) <= 3)
-                metric_add<METRICS>(cfg, s, CTF_M_STEPS_DEFENDING_ZONE, a, 1);
-            if (cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)) <= 3)
-                metric_add<METRICS>(cfg, s, CTF_M_STEPS_ATTACKING_ZONE, a, 1);
-            int adj = 0;
-            const int n_own = cfg_nopp(cfg, 1 - team);
-            for (int q = 0; q < n_own; q++) {  // OPPONENTS[1-team]: own team, self included
-                const int m = cfg_opp(cfg, 1 - team, q);
-                adj += cheb(pr, pc, ps[2 * m], ps[2 * m + 1]) <= 1;
+            // ---- metric-only section (:879-902): one teammate / opponent per sub-lane
+            if (METRICS) {
+                if (cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)) <= 3)
+                    metric_add<METRICS>(cfg, s, CTF_M_STEPS_DEFENDING_ZONE, a, 1);
+                if (cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)) <= 3)
+                    metric_add<METRICS>(cfg, s, CTF_M_STEPS_ATTACKING_ZONE, a, 1);
+                const int n_own = cfg_nopp(cfg, 1 - team), n_opp = cfg_nopp(cfg, team);
+                int adj_own = 0, adj_opp = 0;
+                for (int q = j; q < 8; q += W) {  // lists hold at most 8 agents
+                    bool near_own = false, near_opp = false;
+                    if (q < n_own) {  // OPPONENTS[1-team]: own team, self included
+                        const int mt = cfg_opp(cfg, 1 - team, q);
+                        near_own = cheb(pr, pc, ps[2 * mt], ps[2 * mt + 1]) <= 1;
+                    }
+                    if (q < n_opp) {
+                        const int o = cfg_opp(cfg, team, q);
+                        near_opp = cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1;
+                    }
+                    adj_own += __popc(s.ballot(near_own));
+                    adj_opp += __popc(s.ballot(near_opp));
+                    if (q - j + W >= (n_own > n_opp ? n_own : n_opp)) break;  // group-uniform exit
+                }
+                metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_TEAMMATE, a, adj_own);
+                metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_OPPONENT, a, adj_opp);
             }
-            metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_TEAMMATE, a, adj);
-            adj = 0;
-            const int n_opp = cfg_nopp(cfg, team);
-            for (int q = 0; q < n_opp; q++) {
-                const int o = cfg_opp(cfg, team, q);
-                adj += cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1;
-            }
-            metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_OPPONENT, a, adj);
         }
-    }
-
     }  // phase
 
-    // heal_agents (:839-847), after its shuffle above: heal everyone (order is irrelevant to the result)
-    for (int a = 0; a < N; a++) {  // uniform index: scalar table loads
-        const double mx = cfg.type_hp[cfg.type[a]];
+    // heal_agents (:839-847), after its shuffle above; order is irrelevant to the result: one agent per sub-lane
+    for (int a = j; a < N; a += W) {
+        const double mx = sel4(cfg.type_hp, cfg_type(cfg, a));
         double h = ld_hp(s, a);
         if (h < mx) {
             h += cfg.heal;
@@ -488,63 +547,80 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const StepCtx& s, co
         }
     }
 
-    // rewards: act() reward, + tagging reward, adjusted (:957-966), terminal (:920-940) — same op order
-    const bool terminal = (misc[0] == cfg.game_steps);
+    // rewards: act() reward, + tagging reward, adjusted (:957-966), terminal (:920-940) — same op order; one agent per sub-lane
+    const bool terminal = (step == cfg.game_steps);
     int winner = -1, margin = 0;
     if (terminal) {
-        misc[3] = 1;
-        const int c0 = misc[1], c1 = misc[2];
-        margin = iabs_(c0 - c1);
-        winner = c0 > c1 ? 0 : (c0 < c1 ? 1 : -1);
+        margin = iabs_(caps[0] - caps[1]);
+        winner = caps[0] > caps[1] ? 0 : (caps[0] < caps[1] ? 1 : -1);
     }
+    const int done_now = (misc[3] != 0) || terminal;
+    for (int i = j; i < N; i += W) {
+        const int team = cfg_team(cfg, i);
+        double r = 0.0 + cfg.r_step;
+        if ((cap_mask >> i) & 1u) r += cfg.r_capture;
+        r += ((resp_mask >> i) & 1u) ? cfg.r_tag : 0.0;
+        if (cfg.use_adjusted) r -= (((cap_team >> (1 - team)) & 1u) ? 1.0 : 0.0) * cfg.r_capture * cfg.punish;
+        if (winner >= 0) {
+            if (team == winner) r += margin * cfg.win_scalar;
+            else r -= margin * cfg.loss_scalar;
+        }
+        if (rw32) rw32[(size_t)e * N + i] = (float)r;
+        if (rw64) rw64[(size_t)e * N + i] = r;
+        if (METRICS) {  // update_visitation_map (:479-486); u32 counters, exported modulo 256 (the reference's u8 wraps)
+            atomicAdd(p.vis + ((size_t)e * N + i) * cfg.GS + ps[2 * i] * G + ps[2 * i + 1], 1u);
+        }
+    }
+
+    // ---- the replicated registers go back to the record (sub-lane 0)
+    if (s.lead) {
+        misc[0] = step;
+        misc[1] = caps[0];
+        misc[2] = caps[1];
+        misc[3] = done_now;
+        if (done_out) done_out[e] = (uint8_t)done_now;
 #pragma unroll
-    for (int i = 0; i < CTF_MAX_AGENTS; i++) {
-        if (i < N) {
-            const int team = cfg.team[i];
-            double r = 0.0 + cfg.r_step;
-            if ((cap_mask >> i) & 1u) r += cfg.r_capture;
-            r += ((resp_mask >> i) & 1u) ? cfg.r_tag : 0.0;
-            if (cfg.use_adjusted) r -= (((cap_team >> (1 - team)) & 1u) ? 1.0 : 0.0) * cfg.r_capture * cfg.punish;
-            if (winner >= 0) {
-                if (team == winner) r += margin * cfg.win_scalar;
-                else r -= margin * cfg.loss_scalar;
+        for (int i = 0; i < CTF_MAX_AGENTS; i++) {
+            if (i < N) {
+                s.sr[cfg.off_flag + i] = (uint8_t)((flagm >> i) & 1u);
+                s.sr[cfg.off_perm + i] = (uint8_t)((perm >> (4 * i)) & 15u);
             }
-            rw[i] = r;
         }
     }
 }
 
-template <bool METRICS>
+template <bool METRICS, int W>
 __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
                                                 float* __restrict__ rw32, double* __restrict__ rw64,
                                                 uint8_t* __restrict__ done_out, uint32_t flags) {
+    constexpr int EPW = WAVE / W;  // envs per wave
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
-    const int env0 = blockIdx.x * WAVE;
-    const int nvalid = min(WAVE, cfg.n_envs - env0);
+    const int g = lane / W, j = lane % W;
+    const int env0 = blockIdx.x * EPW;
+    const int nvalid = min(EPW, cfg.n_envs - env0);
     const int SLB = step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     const int SLW = SLB / 4, GW = cfg.GS / 4, RW = cfg.RS / 4;
     const int AW = 4, WW = 2 * WCAP;  // action words, RNG window words per slot
     const int N = cfg.N;
-    const int e = env0 + lane;
+    const int e = env0 + g;
 
-    // ---- stage 64 envs' grids, records and actions into LDS.  Flat, coalesced 16-byte loads, unrolled
-    // so that every lane has 8 independent loads in flight (a rolled per-env loop pays one full memory
-    // latency per env: measured 130 us of a 250 us kernel).
+    // ---- stage the wave's envs' grids, records and actions into LDS.  Flat, coalesced 16-byte loads, unrolled so
+    // that every lane has several independent loads in flight (a rolled per-env loop pays one memory latency per env).
     {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4* gsrc = (const u32x4*)(p.grid + (size_t)env0 * cfg.GS);
         const u32x4* rsrc = (const u32x4*)(p.rec + (size_t)env0 * cfg.RS);
         const int GQ = GW / 4, RQ = RW / 4;  // 16-byte quads per env (GS and RS are multiples of 16)
         const int ng = nvalid * GQ, nr = nvalid * RQ;
-#pragma unroll 8
+#pragma unroll 4
         for (int q = lane; q < ng; q += WAVE) {
             const u32x4 v = gsrc[q];
             const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
             uint32_t* slot = lds + el * SLW + w;
             slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
         }
-#pragma unroll 8
+#pragma unroll 2
         for (int q = lane; q < nr; q += WAVE) {
             const u32x4 v = rsrc[q];
             const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
@@ -552,25 +628,30 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
             slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
         }
         const int8_t* asrc = actions + (size_t)env0 * N;
-#pragma unroll 4
+#pragma unroll 2
         for (int idx = lane; idx < nvalid * N; idx += WAVE) {
             const int el = (int)fdiv((uint32_t)idx, cfg.div_n), i = idx - el * N;
             ((int8_t*)(lds + el * SLW + GW + RW))[i] = asrc[idx];
         }
         if (METRICS) {
             const int MW = (CTF_N_METRICS * N + 3) / 4;
-            for (int el = 0; el < nvalid; el++)
-                for (int w = lane; w < MW; w += WAVE) lds[el * SLW + GW + RW + AW + WW + w] = 0;
+            for (int idx = lane; idx < nvalid * MW; idx += WAVE) {
+                const int el = (int)fdiv((uint32_t)idx, cfg.div_mw), w = idx - el * MW;
+                lds[el * SLW + GW + RW + AW + WW + w] = 0;
+            }
         }
     }
     __syncthreads();
 
-    if (lane < nvalid) {
-        StepCtx s;
-        s.sg = (uint8_t*)(lds + lane * SLW);
+    if (g < nvalid) {
+        StepCtx<W> s;
+        s.sg = (uint8_t*)(lds + g * SLW);
         s.sr = s.sg + cfg.GS;
         uint32_t* wins = (uint32_t*)(s.sr + cfg.RS + 16);
         s.sm = METRICS ? (uint8_t*)(wins + WW) : nullptr;
+        s.j = j;
+        s.gshift = g * W;
+        s.lead = (j == 0);
         const int8_t* act = (const int8_t*)(s.sr + cfg.RS);
         int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
 
@@ -578,58 +659,48 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
         MtWin npg = mtw_open(p.mt_np + (size_t)e * CTF_MT_N, wins + WCAP, p.rngpos[2 * e + 1]);
 
         if ((flags & CTF_STEP_AUTO_RESET) && misc[3]) {
-            // reset() of this env inside the step launch (not in the reference: opt-in flag)
+            // reset() of this env inside the step launch (not in the reference: opt-in flag); the group's lanes share the copies
             const uint32_t* src = (const uint32_t*)p.init_grid;
-            for (int w = 0; w < GW; w++) ((uint32_t*)s.sg)[w] = src[w];
-            reset_record(cfg, s.sr);
+            for (int w = j; w < GW; w += W) ((uint32_t*)s.sg)[w] = src[w];
+            if (s.lead) reset_record(cfg, s.sr);
             if (METRICS) {
                 int32_t* m = p.metrics + (size_t)e * CTF_N_METRICS * N;
-                for (int w = 0; w < CTF_N_METRICS * N; w++) m[w] = 0;
+                for (int w = j; w < CTF_N_METRICS * N; w += W) m[w] = 0;
                 uint32_t* v = p.vis + (size_t)e * N * cfg.GS;
-                for (int w = 0; w < N * cfg.GS; w++) v[w] = 0;
-                for (int i = 0; i < N; i++) v[i * cfg.GS + cfg.start_pos[i][0] * cfg.G + cfg.start_pos[i][1]] = 1;
+                for (int w = j; w < N * cfg.GS; w += W) v[w] = 0;
+                __builtin_amdgcn_s_waitcnt(0);  // the zeroes land before the start cells are marked
+                if (s.lead)
+                    for (int i = 0; i < N; i++) v[i * cfg.GS + cfg.start_pos[i][0] * cfg.G + cfg.start_pos[i][1]] = 1;
             }
         }
 
         uint32_t status = 0;
-        double rw[CTF_MAX_AGENTS];
-        env_step<METRICS>(cfg, s, act, py, npg, status, rw);
-        p.rngpos[2 * e] = mtw_close(py);
-        p.rngpos[2 * e + 1] = mtw_close(npg);
-        if (status) atomicOr(p.status, status);
-
-#pragma unroll
-        for (int i = 0; i < CTF_MAX_AGENTS; i++) {
-            if (i < N) {
-                if (rw32) rw32[(size_t)e * N + i] = (float)rw[i];
-                if (rw64) rw64[(size_t)e * N + i] = rw[i];
-            }
-        }
-        if (done_out) done_out[e] = (uint8_t)misc[3];
-
-        if (METRICS) {  // update_visitation_map (:479-486); u32 counters, exported modulo 256 (the reference's u8 wraps)
-            const int8_t* ps = (const int8_t*)(s.sr + cfg.off_pos);
-            uint32_t* v = p.vis + (size_t)e * N * cfg.GS;
-            for (int i = 0; i < N; i++) atomicAdd(v + i * cfg.GS + ps[2 * i] * cfg.G + ps[2 * i + 1], 1u);
+        env_step<METRICS, W>(cfg, p, s, act, py, npg, status, e, rw32, rw64, done_out);
+        mtw_flush<W>(py, j);
+        mtw_flush<W>(npg, j);
+        if (s.lead) {
+            p.rngpos[2 * e] = py.pos | (py.lazy ? CTF_LAZY_BIT : 0u);
+            p.rngpos[2 * e + 1] = npg.pos | (npg.lazy ? CTF_LAZY_BIT : 0u);
+            if (status) atomicOr(p.status, status);
         }
     }
     __syncthreads();
 
-    // ---- write the 64 envs back (flat, coalesced 16-byte stores)
+    // ---- write the envs back (flat, coalesced 16-byte stores)
     {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         u32x4* gdst = (u32x4*)(p.grid + (size_t)env0 * cfg.GS);
         u32x4* rdst = (u32x4*)(p.rec + (size_t)env0 * cfg.RS);
         const int GQ = GW / 4, RQ = RW / 4;
         const int ng = nvalid * GQ, nr = nvalid * RQ;
-#pragma unroll 4
+#pragma unroll 2
         for (int q = lane; q < ng; q += WAVE) {
             const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
             const uint32_t* slot = lds + el * SLW + w;
             const u32x4 v = {slot[0], slot[1], slot[2], slot[3]};
             gdst[q] = v;
         }
-#pragma unroll 4
+#pragma unroll 2
         for (int q = lane; q < nr; q += WAVE) {
             const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
             const uint32_t* slot = lds + el * SLW + GW + w;
@@ -954,16 +1025,30 @@ extern "C" hipError_t ctf_launch_reset(const DevCfg& cfg, const DevPtrs& p, cons
     hipLaunchKernelGGL(k_reset, dim3(cfg.n_envs), dim3(WAVE), 0, st, cfg, p, mask, init_perm);
     return hipGetLastError();
 }
+template <bool METRICS, int W>
+static void launch_step_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done,
+                          uint32_t flags, hipStream_t st) {
+    constexpr int EPW = WAVE / W;
+    const dim3 grid((cfg.n_envs + EPW - 1) / EPW), block(WAVE);
+    const size_t sh = (size_t)EPW * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
+    hipLaunchKernelGGL((k_step<METRICS, W>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags);
+}
+template <bool METRICS>
+static void launch_step_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
+                          uint8_t* done, uint32_t flags, hipStream_t st) {
+    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, st);
+    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, st);
+    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, st);
+    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, st);
+}
 extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
                                       uint8_t* done, uint32_t flags, hipStream_t st) {
-    const dim3 grid((cfg.n_envs + WAVE - 1) / WAVE), block(WAVE);
-    if (cfg.log_metrics) {
-        const size_t sh = (size_t)WAVE * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, true);
-        hipLaunchKernelGGL(k_step<true>, grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags);
-    } else {
-        const size_t sh = (size_t)WAVE * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, false);
-        hipLaunchKernelGGL(k_step<false>, grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags);
-    }
+    // lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn
+    const int mo = cfg.n_opp[0] > cfg.n_opp[1] ? cfg.n_opp[0] : cfg.n_opp[1];
+    int w = mo <= 1 ? 1 : (mo <= 2 ? 2 : (mo <= 4 ? 4 : 8));
+    if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling knob (CTF_STEP_W), results are identical
+    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, st);
+    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, st);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask,
