@@ -152,17 +152,21 @@ extern "C" __global__ void __launch_bounds__(WAVE) k_reset(DevCfg cfg, DevPtrs p
 // ------------------------------------------------------------------------------------------------
 // lane-divergent config lookups: bit-field extracts / selects on SGPR-resident values (no memory traffic)
 // ------------------------------------------------------------------------------------------------
-// pin*(): pass a kernel-argument value through readfirstlane so that it is an opaque SGPR value.  Without
+// pin*(): pass a kernel-argument value through an empty asm with an SGPR constraint so that it is an opaque SGPR value.  Without
 // this the compiler rewrites "team ? cfg.x[1] : cfg.x[0]" into ONE load from a lane-selected kernarg
 // address, i.e. a dependent vector-memory access in the middle of the per-agent loop.
-__device__ __forceinline__ int pin(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int pin(int v) {
+    asm("" : "+s"(v));  // zero instructions: just makes the value an opaque SGPR operand
+    return v;
+}
 __device__ __forceinline__ uint64_t pin64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
+    asm("" : "+s"(v));
+    return v;
 }
 __device__ __forceinline__ double pind(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    asm("" : "+s"(b));
+    return __longlong_as_double((long long)b);
 }
 __device__ __forceinline__ int cfg_team(const DevCfg& c, int a) { return (int)(((uint32_t)pin((int)c.team_mask) >> a) & 1u); }
 __device__ __forceinline__ int cfg_type(const DevCfg& c, int a) { return (int)(((uint32_t)pin((int)c.type_pack) >> (2 * a)) & 3u); }
@@ -195,6 +199,12 @@ __device__ __forceinline__ double sel4(const double* t, int k) {
 //   [grid GS][rec RS][actions 16][py window 64][np window 64][metric deltas u8 13*N (METRICS)]
 // The slot stride in dwords is odd so that different groups' same-offset accesses fall in distinct banks.
 #define WCAP 16  // MT words per window (>= 2 * max opponents per team)
+// Profiling-only ablations of the step kernel (results become wrong; never defined in the shipped build):
+//   bit0 no tagging, bit1 no metric section, bit2 no shuffles, bit3 no act, bit4 no visitation atomics,
+//   bit5 no metric flush, bit6 no state write-back
+#ifndef STEP_ABLATE
+#define STEP_ABLATE 0
+#endif
 
 __host__ __device__ inline int step_slot_bytes(int GS, int RS, int N, bool metrics) {
     int b = GS + RS + 16 + 2 * WCAP * 4 + (metrics ? ((CTF_N_METRICS * N + 3) & ~3) : 0);
@@ -382,10 +392,12 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
     for (int phase = 0; phase < 2; phase++) {
         // top the CPython window up while the whole wave is at the same point (rejection sampling lets the groups'
         // stream positions diverge; refilling on demand would re-run the refill per group)
+        if (!(STEP_ABLATE & 4)) {
         mtw_flush<W>(py, j);
         mtw_refill<W>(py, j);
+        }
 #pragma unroll 1
-        for (int i = N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
+        for (int i = (STEP_ABLATE & 4) ? 0 : N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
             const uint32_t r = py_randbelow<W>(py, j, (uint32_t)i + 1u);
             const uint64_t vi = (perm >> (4 * i)) & 15u, vr = (perm >> (4 * r)) & 15u;
             perm = (perm & ~((uint64_t)15u << (4 * i)) & ~((uint64_t)15u << (4 * r))) | (vr << (4 * i)) | (vi << (4 * r));
@@ -406,7 +418,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
             const int dc = (base == 2 ? 1 : (base == 3 ? -1 : 0)) * scale;
             int pr = ps[2 * a], pc = ps[2 * a + 1];
             const int nr = pr + dr, nc = pc + dc;
-            if (nr >= 0 && nr < G && nc >= 0 && nc < G) {
+            if (!(STEP_ABLATE & 8) && nr >= 0 && nr < G && nc >= 0 && nc < G) {
                 const int cell = s.sg[nr * G + nc];
                 if (cell == 0 && (action <= 3 || (action >= 5 && type == 2 && (ld_hp(s, a) - cfg.vault_cost) > cfg.vault_min))) {
                     // movement_handler (:569-612)
@@ -469,7 +481,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
 
             // ---- tagging_logic (:796-837): sub-lane q evaluates opponent q0+q; hits are applied in opponent order
             const double dmg = sel4(cfg.type_damage, type);
-            if (dmg > 0) {
+            if (!(STEP_ABLATE & 1) && dmg > 0) {
                 double mult = 1.0;
                 if (type == 1 && cheb(pr, pc, TSEL(cfg.flag_pos, team, 0), TSEL(cfg.flag_pos, team, 1)) <= 3) mult = cfg.guard_mult;
                 const double hit = dmg * mult;
@@ -510,7 +522,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
             }
 
             // ---- metric-only section (:879-902): one teammate / opponent per sub-lane
-            if (METRICS) {
+            if (METRICS && !(STEP_ABLATE & 2)) {
                 if (cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)) <= 3)
                     metric_add<METRICS>(cfg, s, CTF_M_STEPS_DEFENDING_ZONE, a, 1);
                 if (cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)) <= 3)
@@ -567,7 +579,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
         }
         if (rw32) rw32[(size_t)e * N + i] = (float)r;
         if (rw64) rw64[(size_t)e * N + i] = r;
-        if (METRICS) {  // update_visitation_map (:479-486); u32 counters, exported modulo 256 (the reference's u8 wraps)
+        if (METRICS && !(STEP_ABLATE & 16)) {  // update_visitation_map (:479-486); u32 counters, exported modulo 256 (the reference's u8 wraps)
             atomicAdd(p.vis + ((size_t)e * N + i) * cfg.GS + ps[2 * i] * G + ps[2 * i + 1], 1u);
         }
     }
@@ -694,7 +706,7 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
         const int GQ = GW / 4, RQ = RW / 4;
         const int ng = nvalid * GQ, nr = nvalid * RQ;
 #pragma unroll 2
-        for (int q = lane; q < ng; q += WAVE) {
+        for (int q = lane; q < ((STEP_ABLATE & 64) ? 0 : ng); q += WAVE) {
             const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
             const uint32_t* slot = lds + el * SLW + w;
             const u32x4 v = {slot[0], slot[1], slot[2], slot[3]};
@@ -707,7 +719,7 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
             const u32x4 v = {slot[0], slot[1], slot[2], slot[3]};
             rdst[q] = v;
         }
-        if (METRICS) {
+        if (METRICS && !(STEP_ABLATE & 32)) {
             // this step's u8 deltas are added to the i32 counters with no-return atomics: nothing to wait for
             const int MN = CTF_N_METRICS * N;
             int32_t* mdst = p.metrics + (size_t)env0 * MN;
