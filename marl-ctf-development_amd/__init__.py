@@ -15,3 +15,4 @@ or, for drop-in use with the reference's own scripts, put this directory first o
 from . import _abi, config, configs, sharding  # noqa: F401
 from .gridworld_ctf import GridworldCtf, VecGridworldCtf  # noqa: F401
 from .maps import CtfScenarios  # noqa: F401
+from .rollout import BatchedRolloutCollector  # noqa: F401

@@ -1,0 +1,113 @@
+"""Batched rollout collection: the counterpart of ``PPOTrainer.get_single_rollout`` (reference ppo.py:31-131)
+for E envs at once, entirely on the GPU.
+
+What it reproduces from the reference, per env (column ``e`` of every returned tensor is exactly what the
+reference's ``get_single_rollout`` returns for that env, checked against a recorded reference rollout):
+
+* team-0 agents see the raw grid, team-1 agents the flipped one, and team-1 agents' sampled actions are mapped
+  back through ``REVERSED_ACTION_MAP`` before they reach ``step`` (ppo.py:69,80-83,87,90-93) — the stored action is
+  the un-mapped one (ppo.py:77);
+* ``use_action_mask`` per agent type (ppo.py:68,86);
+* only the trained team's (grid, metadata, action, mask, logprob, value, reward) are stored, agent-major inside an env
+  step: slot ``t * A + k`` for the k-th trained agent in ascending agent index (ppo.py:74-84, :105-109), with
+  ``A = N // 2`` and ``num_steps`` env steps per rollout (the reference's ``self.num_steps = args.num_steps * A``);
+* ``dones`` is never written and stays zero (ppo.py:53); ``next_*`` come from the lowest-index trained agent after the
+  last step (ppo.py:117-119), ``next_done`` from the last ``step``.
+
+The policy networks are the caller's (stock PyTorch modules with the reference's
+``get_action_and_value(grid, metadata, use_action_mask)`` signature, agent_network.py:63-81); GAE and the PPO update
+stay the reference's code — they can consume the returned tensors as they are.
+"""
+import numpy as np
+
+try:
+    from .gridworld_ctf import _REVERSED_ACTIONS
+except ImportError:  # pragma: no cover
+    from gridworld_ctf import _REVERSED_ACTIONS
+
+
+class BatchedRolloutCollector:
+    def __init__(self, vec, num_steps, team_to_train, obs_dtype=None):
+        """vec: VecGridworldCtf.  num_steps: ENV steps per rollout (the reference's ``args.num_steps``).
+        obs_dtype: dtype of the stored grid states (default uint8, the env's native output; the reference stores float32)."""
+        import torch
+
+        self.torch = torch
+        self.vec = vec
+        self.T = int(num_steps)
+        self.team = int(team_to_train)
+        n, dev = vec.N_AGENTS, vec.device
+        teams = [vec.AGENT_TEAMS[i] for i in range(n)]
+        types = [vec.AGENT_TYPES[i] for i in range(n)]
+        self.trained = [i for i in range(n) if teams[i] == self.team]
+        self.others = [i for i in range(n) if teams[i] != self.team]
+        self.A = n // 2  # the reference's num_agents_per_team
+        if len(self.trained) != self.A:
+            raise ValueError("teams must be balanced (the reference assumes N // 2 trained agents)")
+        self.trained_idx = torch.tensor(self.trained, device=dev)
+        self.others_idx = torch.tensor(self.others, device=dev)
+        flag = {0: 1.0, 1: 1.0, 2: 0.0, 3: 0.0}  # AGENT_TYPE_ACTION_MASK (gridworld_ctf.py:218-223)
+        self.mask_flag = torch.tensor([flag[t] for t in types], dtype=torch.float32, device=dev)
+        flip = vec.derived["flip_axis"]
+        self.rev_lut = torch.tensor(_REVERSED_ACTIONS[flip], dtype=torch.int8, device=dev)
+        self.is_team1 = torch.tensor([t == 1 for t in teams], device=dev)
+        self.obs_dtype = obs_dtype or torch.uint8
+        E, S = vec.n_envs, self.T * self.A
+        c, g, m = vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN
+        self.grid_states = torch.zeros((S, E, c, g, g), dtype=self.obs_dtype, device=dev)
+        self.metadata_states = torch.zeros((S, E, m), dtype=torch.float32, device=dev)
+        self.actions = torch.zeros((S, E), dtype=torch.float32, device=dev)
+        self.use_action_mask = torch.zeros((S, E), dtype=torch.float32, device=dev)
+        self.logprobs = torch.zeros((S, E), dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros((S, E), dtype=torch.float32, device=dev)
+        self.dones = torch.zeros((S, E), dtype=torch.float32, device=dev)
+        self.values = torch.zeros((S, E), dtype=torch.float32, device=dev)
+        self._env_actions = torch.zeros((E, n), dtype=torch.int8, device=dev)
+
+    def _policy(self, net, obs, meta, idx):
+        """Run one policy over agents `idx` of every env: batch = E * len(idx), agent-major."""
+        torch = self.torch
+        E = self.vec.n_envs
+        grid = obs.index_select(1, idx).transpose(0, 1).reshape((-1,) + tuple(obs.shape[2:])).to(torch.float32)
+        md = meta.index_select(1, idx).transpose(0, 1).reshape(-1, meta.shape[2]).to(torch.float32)
+        mask = self.mask_flag.index_select(0, idx)[:, None].expand(-1, E).reshape(-1)
+        action, logprob, _, value = net.get_action_and_value(grid, md, mask)
+        k = idx.numel()
+        return (action.reshape(k, E), logprob.reshape(k, E), value.reshape(k, E), grid.reshape((k, E) + tuple(obs.shape[2:])),
+                md.reshape(k, E, -1), mask.reshape(k, E))
+
+    def collect(self, agent, opponent, reset=True):
+        """-> dict with the tensors ``get_single_rollout`` returns, each with an env axis after the slot axis."""
+        torch, vec, A = self.torch, self.vec, self.A
+        if reset:
+            vec.reset()  # ppo.py:57
+        self.dones.zero_()
+        done = None
+        with torch.no_grad():
+            for t in range(self.T):
+                obs, meta = vec.observe()  # default reversal: team(i) == 1
+                a_act, a_lp, a_val, a_grid, a_md, a_mask = self._policy(agent, obs, meta, self.trained_idx)
+                o_act = self._policy(opponent, obs, meta, self.others_idx)[0]
+                sl = slice(t * A, (t + 1) * A)
+                self.grid_states[sl] = a_grid.to(self.obs_dtype)
+                self.metadata_states[sl] = a_md
+                self.values[sl] = a_val
+                self.actions[sl] = a_act.to(torch.float32)
+                self.use_action_mask[sl] = a_mask
+                self.logprobs[sl] = a_lp
+                # actions as the env sees them: team-1 agents' actions are mapped back through the flip
+                env_act = self._env_actions
+                env_act[:, self.trained_idx] = a_act.to(torch.int8).transpose(0, 1)
+                env_act[:, self.others_idx] = o_act.to(torch.int8).transpose(0, 1)
+                mapped = self.rev_lut[env_act.long()]
+                env_act = torch.where(self.is_team1[None, :], mapped, env_act).contiguous()
+                rewards, done = vec.step(env_act)
+                self.rewards[sl] = rewards.index_select(1, self.trained_idx).transpose(0, 1)
+            obs, meta = vec.observe()
+            first = self.trained[0]
+            next_grid = obs[:, first].to(torch.float32)
+            next_meta = meta[:, first].to(torch.float32)
+            next_done = done.to(torch.float32)
+        return dict(grid_states=self.grid_states, metadata_states=self.metadata_states, actions=self.actions,
+                    use_action_mask=self.use_action_mask, logprobs=self.logprobs, rewards=self.rewards, dones=self.dones,
+                    values=self.values, next_grid_state=next_grid, next_metadata_state=next_meta, next_done=next_done)

@@ -16,7 +16,12 @@ maps = importlib.import_module("marl-ctf-development_amd.maps").CtfScenarios
 
 
 def case_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("maps_ref.npz"))
+    names = (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return sorted(n for n in names if n != "maps_ref" and not n.startswith("rollout_"))
+
+
+def rollout_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "rollout_*.npz")))
 
 
 def _intkeys(d):

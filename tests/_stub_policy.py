@@ -1,0 +1,29 @@
+"""A deterministic stand-in for the reference's policy network (agent_network.py:63-81) used to pin the rollout
+layout: every output is an exact function of the observation, identical whether called per agent (batch of 1, as
+ppo.py does) or for thousands of envs at once."""
+import torch
+
+
+class StubPolicy:
+    def __init__(self, salt, n_actions=9):
+        self.salt, self.n_actions = int(salt), int(n_actions)
+
+    def _score(self, x):
+        c, g = x.shape[-3], x.shape[-1]
+        ci = torch.arange(c, device=x.device, dtype=torch.float32).view(c, 1, 1)
+        yi = torch.arange(g, device=x.device, dtype=torch.float32).view(1, g, 1)
+        xi = torch.arange(g, device=x.device, dtype=torch.float32).view(1, 1, g)
+        w = torch.remainder(ci * 31 + yi * 7 + xi * 3 + self.salt, 11.0) + 1.0  # small integers: sums are exact in f32
+        return (x.to(torch.float32) * w).sum(dim=(-3, -2, -1))
+
+    def get_action_and_value(self, x, x2, masking_decision_tensor, action=None):
+        x = x.reshape((-1,) + tuple(x.shape[-3:]))
+        x2 = x2.reshape(x.shape[0], -1)
+        s = self._score(x)
+        mask = masking_decision_tensor.reshape(-1).to(torch.float32).expand(x.shape[0]) if masking_decision_tensor.numel() == 1 \
+            else masking_decision_tensor.reshape(-1).to(torch.float32)
+        n_allowed = torch.where(mask == 1, torch.full_like(s, 5.0), torch.full_like(s, float(self.n_actions)))
+        act = torch.remainder(s, n_allowed).to(torch.int64)
+        logprob = -torch.remainder(s, 7.0) / 8.0
+        value = (torch.remainder(s, 13.0) / 16.0 + x2[:, 0].to(torch.float32) * 2.0).reshape(-1, 1)
+        return act, logprob, torch.zeros_like(logprob), value
