@@ -195,7 +195,7 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
 static void free_all(ctf_env* h) {
     if (!h) return;
     (void)hipFree(h->p.grid); (void)hipFree(h->p.rec); (void)hipFree(h->p.mt_py); (void)hipFree(h->p.mt_np);
-    (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis);
+    (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis); (void)hipFree(h->p.vislog);
     (void)hipFree((void*)h->p.init_grid); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
     delete h;
 }
@@ -230,6 +230,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     ALLOC(h->p.rngpos, E * 2 * 4);
     ALLOC(h->p.metrics, met_elems * 4);
     ALLOC(h->p.vis, vis_elems * 4);
+    ALLOC(h->p.vislog, (d.log_metrics ? (size_t)CTF_VIS_LOG * E * d.N : 1) * 2);
     ALLOC(h->p.init_grid, (size_t)d.GS);
     ALLOC(h->p.status, 4);
     ALLOC(h->seed_scratch, E * 2 * 8);
@@ -399,16 +400,42 @@ extern "C" int ctf_get_state(ctf_env* h, int32_t e, ctf_state_view* out) {
     out->step_count = misc[0];
     out->team_captures[0] = misc[1];
     out->team_captures[1] = misc[2];
-    out->done = misc[3];
+    out->done = (misc[3] & CTF_F_DONE) ? 1 : 0;
     if (d.log_metrics) {
         std::vector<int32_t> m((size_t)CTF_N_METRICS * d.N);
         HIP_TRY(hipMemcpy(m.data(), h->p.metrics + (size_t)e * CTF_N_METRICS * d.N, m.size() * 4, hipMemcpyDeviceToHost));
         for (int k = 0; k < CTF_N_METRICS; k++)
             for (int i = 0; i < d.N; i++) out->metrics[k][i] = m[(size_t)k * d.N + i];
-        std::vector<uint32_t> v((size_t)d.N * d.GS);
-        HIP_TRY(hipMemcpy(v.data(), h->p.vis + (size_t)e * d.N * d.GS, v.size() * 4, hipMemcpyDeviceToHost));
+        // visitation maps = base maps (or zeros + 1 at the start cells while nothing has been folded) + the log
+        // entries of steps (folded, step_count]; u8 wrap as in the reference
+        std::vector<uint32_t> v((size_t)d.N * d.GS, 0);
+        if (misc[3] & CTF_F_BASE_ZERO) {
+            for (int i = 0; i < d.N; i++) v[(size_t)i * d.GS + d.start_pos[i][0] * d.G + d.start_pos[i][1]] = 1;  // reset(): :473
+        } else {
+            HIP_TRY(hipMemcpy(v.data(), h->p.vis + (size_t)e * d.N * d.GS, v.size() * 4, hipMemcpyDeviceToHost));
+        }
+        const int folded = misc[3] >> CTF_F_FOLDED_SHIFT;
+        const int count = misc[0] - folded;  // <= CTF_VIS_LOG - 1 entries, slots (folded+1 .. step) mod 512
+        if (count > 0) {
+            std::vector<uint16_t> entries((size_t)count * d.N);
+            const size_t pitch = (size_t)d.n_envs * d.N * 2, width = (size_t)d.N * 2;
+            int done_rows = 0;
+            while (done_rows < count) {  // at most two runs: the ring may wrap
+                const int slot = (folded + 1 + done_rows) & (CTF_VIS_LOG - 1);
+                const int rows = (count - done_rows) < (CTF_VIS_LOG - slot) ? (count - done_rows) : (CTF_VIS_LOG - slot);
+                HIP_TRY(hipMemcpy2D(entries.data() + (size_t)done_rows * d.N, width,
+                                    h->p.vislog + ((size_t)slot * d.n_envs + e) * d.N, pitch, width, (size_t)rows,
+                                    hipMemcpyDeviceToHost));
+                done_rows += rows;
+            }
+            for (int r = 0; r < count; r++)
+                for (int i = 0; i < d.N; i++) {
+                    const uint16_t cell = entries[(size_t)r * d.N + i];
+                    if (cell < (uint16_t)d.GG) v[(size_t)i * d.GS + cell]++;
+                }
+        }
         for (int i = 0; i < d.N; i++)
-            for (int k = 0; k < d.GG; k++) out->visitation[i][k] = (uint8_t)(v[(size_t)i * d.GS + k] & 0xFFu);  // u8 wraps in the reference
+            for (int k = 0; k < d.GG; k++) out->visitation[i][k] = (uint8_t)(v[(size_t)i * d.GS + k] & 0xFFu);
     }
     return CTF_OK;
 }
@@ -426,6 +453,7 @@ extern "C" int ctf_set_state(ctf_env* h, int32_t e, const ctf_state_view* in) {
     }
     for (int k = 0; k < d.GG; k++)
         if (in->grid[k] > 13) return fail(CTF_E_INVALID, "grid[%d]", k);
+    if (in->step_count < 0 || in->step_count >= (1 << 28)) return fail(CTF_E_INVALID, "step_count %d", in->step_count);
     HIP_TRY(hipDeviceSynchronize());
     std::vector<uint8_t> rec((size_t)d.RS, 0), grid((size_t)d.GS, 0);
     memcpy(grid.data(), in->grid, (size_t)d.GG);
@@ -438,7 +466,9 @@ extern "C" int ctf_set_state(ctf_env* h, int32_t e, const ctf_state_view* in) {
         const int16_t inv = (int16_t)in->inventory[i];
         memcpy(rec.data() + d.off_inv + 2 * i, &inv, 2);
     }
-    const int32_t misc[4] = {in->step_count, in->team_captures[0], in->team_captures[1], in->done ? 1 : 0};
+    // the given visitation maps become the base maps; the log is empty (folded up to step_count)
+    const int32_t misc[4] = {in->step_count, in->team_captures[0], in->team_captures[1],
+                             (in->done ? CTF_F_DONE : 0) | (d.log_metrics ? 0 : CTF_F_BASE_ZERO) | (in->step_count << CTF_F_FOLDED_SHIFT)};
     memcpy(rec.data() + d.off_misc, misc, 16);
     HIP_TRY(hipMemcpy(h->p.grid + (size_t)e * d.GS, grid.data(), (size_t)d.GS, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->p.rec + (size_t)e * d.RS, rec.data(), (size_t)d.RS, hipMemcpyHostToDevice));

@@ -6,12 +6,16 @@
 //   grid   u8  [E][GS]        GS = G*G rounded up to 16; row-major tile codes (reference self.grid)
 //   rec    u8  [E][RS]        one record per env, RS multiple of 16:
 //                               f64 hp[N] | i8 pos[N][2] | u8 has_flag[N] | u8 perm[N] | i16 inv[N]
-//                               | i32 step | i32 caps[2] | u8 done | pad
+//                               | i32 step | i32 caps[2] | i32 flags (done, visitation log state)
 //   mt_py  u32 [E][624]       CPython `random` stream   (MT19937, lazily regenerated in place)
 //   mt_np  u32 [E][624]       NumPy legacy `np.random` stream
 //   rngpos u32 [E][2]         per stream: position (0..624) | lazy-flag << 16
 //   metric i32 [E][13][N]     agent-level counters (only when log_metrics)
-//   vis    u32 [E][N][GS]     visitation counters  (only when log_metrics; exported modulo 256)
+//   vislog u16 [512][E][N]    visitation LOG: entry (step % 512) = the cell of every agent after that step; the
+//                             maps are rebuilt from it on export, so a step writes 2N coalesced bytes per env
+//                             instead of N scattered read-modify-writes (only when log_metrics)
+//   vis    u32 [E][N][GS]     visitation BASE maps: what has been folded out of the log (an env that is not reset
+//                             for 511 steps folds its own log in-kernel) or handed in by ctf_set_state
 #pragma once
 #include <stdint.h>
 
@@ -57,10 +61,17 @@ struct DevPtrs {
     uint32_t* mt_np;
     uint32_t* rngpos;
     int32_t* metrics;
-    uint32_t* vis;             // u32 counters [E][N][GS]; the reference's u8 maps are these modulo 256
+    uint32_t* vis;             // base maps u32 [E][N][GS]; valid only when the env's CTF_F_BASE_ZERO flag is clear
+    uint16_t* vislog;          // u16 [CTF_VIS_LOG][E][N]
     const uint8_t* init_grid;  // GS bytes
     uint32_t* status;
 };
 
+// rec.misc[3]: bit 0 done, bit 1 base maps are implicitly zero (+1 at the start cells), bits 2.. = last step whose
+// log entry has been folded into the base maps
+#define CTF_F_DONE 1
+#define CTF_F_BASE_ZERO 2
+#define CTF_F_FOLDED_SHIFT 2
+#define CTF_VIS_LOG 512
 #define CTF_POS_MASK 0xFFFFu
 #define CTF_LAZY_BIT 0x10000u

@@ -123,7 +123,7 @@ __device__ __forceinline__ void reset_record(const DevCfg& cfg, BytePtr sr) {
     misc[0] = 0;  // env_step_count
     misc[1] = 0;  // team_flag_captures[0]
     misc[2] = 0;  // team_flag_captures[1]
-    misc[3] = 0;  // done
+    misc[3] = CTF_F_BASE_ZERO;  // not done; visitation = zero maps + the start cells (:473), log empty
 }
 
 // One 64-lane block per env; mask == nullptr resets every env.  init_perm is set only by ctf_create.
@@ -142,10 +142,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) k_reset(DevCfg cfg, DevPtrs p
     if (cfg.log_metrics) {
         int32_t* m = p.metrics + (size_t)e * CTF_N_METRICS * cfg.N;
         for (int w = lane; w < CTF_N_METRICS * cfg.N; w += WAVE) m[w] = 0;
-        uint32_t* v = p.vis + (size_t)e * cfg.N * cfg.GS;
-        for (int w = lane; w < cfg.N * cfg.GS; w += WAVE) v[w] = 0;
-        __syncthreads();
-        if (lane < cfg.N) v[lane * cfg.GS + cfg.start_pos[lane][0] * cfg.G + cfg.start_pos[lane][1]] = 1;  // :473
+        // visitation: reset_record flagged the base maps as zero and emptied the log — nothing to clear
     }
 }
 
@@ -375,6 +372,20 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
     // replicated register copies of the small per-env state: step, captures, has_flag bits, _arr as nibbles
     const int step = misc[0] + 1;
     int caps[2] = {misc[1], misc[2]};
+    int vis_flags = misc[3];
+    if (METRICS && (step - 1) - (vis_flags >> CTF_F_FOLDED_SHIFT) >= CTF_VIS_LOG - 1) {
+        // the env went 511 steps without a reset: fold its log into the base maps before entry `step` reuses a slot
+        uint32_t* base = p.vis + (size_t)e * N * cfg.GS;
+        if (vis_flags & CTF_F_BASE_ZERO) {
+            for (int w = j; w < N * cfg.GS; w += W) base[w] = 0;
+            __builtin_amdgcn_s_waitcnt(0);
+            for (int i = j; i < N; i += W) atomicAdd(base + i * cfg.GS + cfg.start_pos[i][0] * G + cfg.start_pos[i][1], 1u);
+        }
+        for (int st = (vis_flags >> CTF_F_FOLDED_SHIFT) + 1; st <= step - 1; st++)
+            for (int i = j; i < N; i += W)
+                atomicAdd(base + i * cfg.GS + p.vislog[((size_t)(st & (CTF_VIS_LOG - 1)) * cfg.n_envs + e) * N + i], 1u);
+        vis_flags = (vis_flags & CTF_F_DONE) | ((step - 1) << CTF_F_FOLDED_SHIFT);
+    }
     uint32_t flagm = 0;
     uint64_t perm = 0;
 #pragma unroll
@@ -566,7 +577,8 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
         margin = iabs_(caps[0] - caps[1]);
         winner = caps[0] > caps[1] ? 0 : (caps[0] < caps[1] ? 1 : -1);
     }
-    const int done_now = (misc[3] != 0) || terminal;
+    const int flags_in = misc[3];
+    const int done_now = ((flags_in & CTF_F_DONE) != 0) || terminal;
     for (int i = j; i < N; i += W) {
         const int team = cfg_team(cfg, i);
         double r = 0.0 + cfg.r_step;
@@ -579,8 +591,8 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
         }
         if (rw32) rw32[(size_t)e * N + i] = (float)r;
         if (rw64) rw64[(size_t)e * N + i] = r;
-        if (METRICS && !(STEP_ABLATE & 16)) {  // update_visitation_map (:479-486); u32 counters, exported modulo 256 (the reference's u8 wraps)
-            atomicAdd(p.vis + ((size_t)e * N + i) * cfg.GS + ps[2 * i] * G + ps[2 * i + 1], 1u);
+        if (METRICS && !(STEP_ABLATE & 16)) {  // update_visitation_map (:479-486) as a log entry: slot step % 512
+            p.vislog[((size_t)(step & (CTF_VIS_LOG - 1)) * cfg.n_envs + e) * N + i] = (uint16_t)(ps[2 * i] * G + ps[2 * i + 1]);
         }
     }
 
@@ -589,7 +601,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
         misc[0] = step;
         misc[1] = caps[0];
         misc[2] = caps[1];
-        misc[3] = done_now;
+        misc[3] = (vis_flags & ~CTF_F_DONE) | (done_now ? CTF_F_DONE : 0);
         if (done_out) done_out[e] = (uint8_t)done_now;
 #pragma unroll
         for (int i = 0; i < CTF_MAX_AGENTS; i++) {
@@ -670,7 +682,7 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
         MtWin py = mtw_open(p.mt_py + (size_t)e * CTF_MT_N, wins, p.rngpos[2 * e]);
         MtWin npg = mtw_open(p.mt_np + (size_t)e * CTF_MT_N, wins + WCAP, p.rngpos[2 * e + 1]);
 
-        if ((flags & CTF_STEP_AUTO_RESET) && misc[3]) {
+        if ((flags & CTF_STEP_AUTO_RESET) && (misc[3] & CTF_F_DONE)) {
             // reset() of this env inside the step launch (not in the reference: opt-in flag); the group's lanes share the copies
             const uint32_t* src = (const uint32_t*)p.init_grid;
             for (int w = j; w < GW; w += W) ((uint32_t*)s.sg)[w] = src[w];
@@ -678,11 +690,7 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
             if (METRICS) {
                 int32_t* m = p.metrics + (size_t)e * CTF_N_METRICS * N;
                 for (int w = j; w < CTF_N_METRICS * N; w += W) m[w] = 0;
-                uint32_t* v = p.vis + (size_t)e * N * cfg.GS;
-                for (int w = j; w < N * cfg.GS; w += W) v[w] = 0;
-                __builtin_amdgcn_s_waitcnt(0);  // the zeroes land before the start cells are marked
-                if (s.lead)
-                    for (int i = 0; i < N; i++) v[i * cfg.GS + cfg.start_pos[i][0] * cfg.G + cfg.start_pos[i][1]] = 1;
+                // (visitation: reset_record flagged the base maps as zero and emptied the log)
             }
         }
 
