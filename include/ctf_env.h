@@ -184,6 +184,12 @@ int ctf_action_mask(const ctf_env* env, uint8_t* mask_host);
 int ctf_get_state(ctf_env* env, int32_t env_index, ctf_state_view* host_out);
 int ctf_set_state(ctf_env* env, int32_t env_index, const ctf_state_view* host_in);
 
+/* Bulk export of the counters the duel / evaluation harness reads (utils.py:557-571, metrics_logger.py:137-159):
+ *   metrics_dev   int32 [E][13][N] agent-level counters (CTF_M_* order) or NULL (zeros when log_metrics == 0)
+ *   captures_dev  int32 [E][2]     metrics['team_flag_captures'] or NULL
+ *   steps_dev     int32 [E]        env_step_count or NULL */
+int ctf_export_counters(ctf_env* env, int32_t* metrics_dev, int32_t* captures_dev, int32_t* steps_dev, void* stream);
+
 /* Sticky status bits raised by any env since the last call (synchronises `stream`, clears them). */
 int ctf_status(ctf_env* env, uint32_t* out_bits, void* stream);
 

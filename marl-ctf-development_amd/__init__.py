@@ -16,3 +16,4 @@ from . import _abi, config, configs, sharding  # noqa: F401
 from .gridworld_ctf import GridworldCtf, VecGridworldCtf  # noqa: F401
 from .maps import CtfScenarios  # noqa: F401
 from .rollout import BatchedRolloutCollector  # noqa: F401
+from .duel import batched_duel  # noqa: F401

@@ -19,6 +19,7 @@ extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint
 extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
 
 struct ctf_env {
     ctf_config cfg;
@@ -482,6 +483,14 @@ extern "C" int ctf_set_state(ctf_env* h, int32_t e, const ctf_state_view* in) {
             for (int k = 0; k < d.GG; k++) v[(size_t)i * d.GS + k] = in->visitation[i][k];
         HIP_TRY(hipMemcpy(h->p.vis + (size_t)e * d.N * d.GS, v.data(), v.size() * 4, hipMemcpyHostToDevice));
     }
+    return CTF_OK;
+}
+
+extern "C" int ctf_export_counters(ctf_env* h, int32_t* metrics_dev, int32_t* captures_dev, int32_t* steps_dev, void* stream) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (!metrics_dev && !captures_dev && !steps_dev) return CTF_OK;
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_export_counters(h->d, h->p, metrics_dev, captures_dev, steps_dev, (hipStream_t)stream));
     return CTF_OK;
 }
 

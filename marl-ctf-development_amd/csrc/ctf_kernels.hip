@@ -728,13 +728,23 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
             rdst[q] = v;
         }
         if (METRICS && !(STEP_ABLATE & 32)) {
-            // this step's u8 deltas are added to the i32 counters with no-return atomics: nothing to wait for
+            // this step's u8 deltas are added to the i32 counters with no-return atomics (nothing to wait for); two
+            // neighbouring counters share one 64-bit add (a counter never carries out of its 32 bits)
             const int MN = CTF_N_METRICS * N;
             int32_t* mdst = p.metrics + (size_t)env0 * MN;
-            for (int idx = lane; idx < nvalid * MN; idx += WAVE) {
-                const int el = (int)fdiv((uint32_t)idx, cfg.div_mn), w = idx - el * MN;
-                const uint8_t inc = ((const uint8_t*)(lds + el * SLW + GW + RW + AW + WW))[w];
-                if (inc) atomicAdd(mdst + idx, (int32_t)inc);
+            if ((MN & 1) == 0) {
+                for (int idx = lane; idx < nvalid * MN / 2; idx += WAVE) {
+                    const int el = (int)fdiv((uint32_t)(2 * idx), cfg.div_mn), w = 2 * idx - el * MN;
+                    const uint8_t* d = (const uint8_t*)(lds + el * SLW + GW + RW + AW + WW) + w;
+                    const unsigned long long inc = (unsigned long long)d[0] | ((unsigned long long)d[1] << 32);
+                    if (inc) atomicAdd((unsigned long long*)(mdst + 2 * idx), inc);
+                }
+            } else {
+                for (int idx = lane; idx < nvalid * MN; idx += WAVE) {
+                    const int el = (int)fdiv((uint32_t)idx, cfg.div_mn), w = idx - el * MN;
+                    const uint8_t inc = ((const uint8_t*)(lds + el * SLW + GW + RW + AW + WW))[w];
+                    if (inc) atomicAdd(mdst + idx, (int32_t)inc);
+                }
             }
         }
     }
@@ -1007,6 +1017,22 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// bulk export of the evaluation counters
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void k_export_counters(DevCfg cfg, DevPtrs p, int32_t* metrics, int32_t* captures, int32_t* steps) {
+    const int MN = CTF_N_METRICS * cfg.N;
+    const size_t total = (size_t)cfg.n_envs * MN;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        if (metrics) metrics[idx] = cfg.log_metrics ? p.metrics[idx] : 0;
+        if (idx < (size_t)cfg.n_envs) {
+            const int32_t* misc = (const int32_t*)(p.rec + idx * cfg.RS + cfg.off_misc);
+            if (captures) { captures[2 * idx] = misc[1]; captures[2 * idx + 1] = misc[2]; }
+            if (steps) steps[idx] = misc[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic actions: Philox4x32-10 (Salmon et al. 2011), one lane per (env, block of 8 agents)
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void k_random_actions(DevCfg cfg, int8_t* actions, uint64_t seed, uint32_t step, uint32_t env_offset) {
@@ -1089,6 +1115,14 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
         hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     else
         hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
+    return hipGetLastError();
+}
+extern "C" hipError_t ctf_launch_export_counters(const DevCfg& cfg, const DevPtrs& p, int32_t* metrics, int32_t* captures, int32_t* steps,
+                                                 hipStream_t st) {
+    const size_t total = (size_t)cfg.n_envs * CTF_N_METRICS * cfg.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_export_counters, dim3(blocks), dim3(256), 0, st, cfg, p, metrics, captures, steps);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg& cfg, int8_t* actions, uint64_t seed, uint32_t step,

@@ -1,0 +1,38 @@
+"""Batched duel: the counterpart of ``utils.duel`` (reference utils.py:500-573) for E envs at once.
+
+Per env it reproduces the reference loop: ``reset()``; every step each agent observes (team 0 raw, team 1 flipped),
+team-0 agents are driven by ``agent`` and team-1 agents by ``opponent`` whose actions are mapped back through
+``REVERSED_ACTION_MAP`` (utils.py:535-551); the loop ends when the env reports ``done`` or after ``max_steps + 1``
+steps (``step_count > max_steps``, utils.py:559).  All envs of a batch share GAME_STEPS and start together, so they
+all stop at the same step.  Returns what the reference returns per env: the result sign (utils.py:562-569) and the
+counters ``env.metrics`` holds (as tensors; ``VecGridworldCtf.counters``).
+"""
+try:
+    from .rollout import BatchedRolloutCollector
+except ImportError:  # pragma: no cover
+    from rollout import BatchedRolloutCollector
+
+
+def batched_duel(vec, agent, opponent, max_steps=256):
+    """-> dict(result int8 [E] (+1 team 0 wins, 0 draw, -1 team 1 wins), team_flag_captures int32 [E, 2],
+    metrics int32 [E, 13, N], steps int)."""
+    import torch
+
+    col = BatchedRolloutCollector(vec, 1, 0)  # reuses the policy plumbing; its rollout buffers hold one step
+    game_steps = int(vec.cfg.game_steps)
+    n_steps = min(game_steps, int(max_steps) + 1)
+    vec.reset()
+    with torch.no_grad():
+        for _ in range(n_steps):
+            obs, meta = vec.observe()
+            a0 = col._policy(agent, obs, meta, col.trained_idx)[0]
+            a1 = col._policy(opponent, obs, meta, col.others_idx)[0]
+            env_act = col._env_actions
+            env_act[:, col.trained_idx] = a0.to(torch.int8).transpose(0, 1)
+            env_act[:, col.others_idx] = a1.to(torch.int8).transpose(0, 1)
+            mapped = col.rev_lut[env_act.long()]
+            env_act = torch.where(col.is_team1[None, :], mapped, env_act).contiguous()
+            vec.step(env_act)
+    metrics, caps, _ = vec.counters()
+    result = torch.sign(caps[:, 0] - caps[:, 1]).to(torch.int8)
+    return dict(result=result, team_flag_captures=caps, metrics=metrics, steps=n_steps)

@@ -160,6 +160,18 @@ class VecGridworldCtf:
         _abi.check(self._lib.ctf_random_actions(self._h, a, int(seed), int(step), int(env_offset), self._stream()), self._lib)
         return out
 
+    def counters(self):
+        """-> (metrics int32 [E, 13, N] in _abi.METRIC_NAMES order, team_flag_captures int32 [E, 2], env_step_count int32 [E]):
+        what utils.duel / MetricsLogger.harvest_metrics read from ``env.metrics``, for every env at once."""
+        torch = _torch()
+        E, N = self.n_envs, self.N_AGENTS
+        met = torch.empty((E, _abi.N_METRICS, N), dtype=torch.int32, device=self.device)
+        caps = torch.empty((E, 2), dtype=torch.int32, device=self.device)
+        steps = torch.empty((E,), dtype=torch.int32, device=self.device)
+        _abi.check(self._lib.ctf_export_counters(self._h, C.c_void_p(met.data_ptr()), C.c_void_p(caps.data_ptr()),
+                                                 C.c_void_p(steps.data_ptr()), self._stream()), self._lib)
+        return met, caps, steps
+
     def action_mask(self):
         """uint8 [N, 9]: 1 where the action is legal for the agent's type (agent_network.py:66-75)."""
         m = np.zeros((self.N_AGENTS, _abi.N_ACTIONS), np.uint8)

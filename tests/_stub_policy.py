@@ -27,3 +27,10 @@ class StubPolicy:
         logprob = -torch.remainder(s, 7.0) / 8.0
         value = (torch.remainder(s, 13.0) / 16.0 + x2[:, 0].to(torch.float32) * 2.0).reshape(-1, 1)
         return act, logprob, torch.zeros_like(logprob), value
+
+
+class StubDuelPolicy(StubPolicy):
+    """The same stub with the single-observation ``get_action`` the reference's duel harness calls (agent_network.py:42-58)."""
+
+    def get_action(self, x, x2, masking_decision_tensor):
+        return int(self.get_action_and_value(x, x2, masking_decision_tensor)[0].reshape(-1)[0].item())
