@@ -36,12 +36,15 @@ class RolloutGather:
         import torch
 
         self.world, self.group = world, group
-        self.bufs = []
+        self.bufs, self.src = [], []
         for _ in range(2):
             self.bufs.append((
                 torch.empty((world * rewards.shape[0],) + tuple(rewards.shape[1:]), dtype=rewards.dtype, device=rewards.device),
                 torch.empty((world * done.shape[0],), dtype=done.dtype, device=done.device),
             ))
+            # the env overwrites its rewards / done buffers on the next step while a gather may still be reading:
+            # every in-flight gather reads from its own snapshot
+            self.src.append((torch.empty_like(rewards), torch.empty_like(done)))
         self.pending = [None, None]
         self.k = 0
 
@@ -56,8 +59,11 @@ class RolloutGather:
             gr.copy_(rewards, non_blocking=True)
             gd.copy_(done, non_blocking=True)
         else:
-            w1 = dist.all_gather_into_tensor(gr, rewards.contiguous(), group=self.group, async_op=True)
-            w2 = dist.all_gather_into_tensor(gd, done.contiguous(), group=self.group, async_op=True)
+            sr, sd = self.src[slot]
+            sr.copy_(rewards, non_blocking=True)
+            sd.copy_(done, non_blocking=True)
+            w1 = dist.all_gather_into_tensor(gr, sr, group=self.group, async_op=True)
+            w2 = dist.all_gather_into_tensor(gd, sd, group=self.group, async_op=True)
             self.pending[slot] = (w1, w2)
         self.k += 1
         return slot
