@@ -817,6 +817,165 @@ __device__ __forceinline__ uint32_t expand4(uint32_t h, int j) {
     return (((h >> (4 * j)) & 15u) * 0x00204081u) & 0x01010101u;
 }
 
+struct ObsSlots {  // which agents look through each (viewer team, reversed?) view — uniform over the launch
+    uint32_t a[4];
+};
+__device__ __forceinline__ ObsSlots obs_slots(const DevCfg& cfg, uint32_t reverse_mask) {
+    ObsSlots s = {{0, 0, 0, 0}};
+    for (int i = 0; i < cfg.N; i++) {
+        const int sl = cfg.team[i] * 2 + (int)((reverse_mask >> i) & 1u);
+        s.a[0] |= (sl == 0) ? (1u << i) : 0u;
+        s.a[1] |= (sl == 1) ? (1u << i) : 0u;
+        s.a[2] |= (sl == 2) ? (1u << i) : 0u;
+        s.a[3] |= (sl == 3) ? (1u << i) : 0u;
+    }
+    return s;
+}
+
+// Everything of one env except the streaming: bitmap (zero + hot bits + own-position bits) into `bits`, metadata rows
+// to global memory.  `recw` / `cells` are the lane's dword of the env's record / grid (lane-clamped loads).
+// srec / mv / mstage are the calling wave's scratch.  Ends with the wave's LDS traffic drained.
+__device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& p, int e, uint32_t recw, uint32_t cells,
+                                              uint8_t* srec, uint16_t* mv, uint16_t* mstage, uint32_t* bits,
+                                              const ObsSlots& slots, uint32_t reverse_mask, int lane, bool obs,
+                                              uint16_t* __restrict__ meta) {
+    const int N = cfg.N, G = cfg.G, GG = cfg.GG, M = cfg.M;
+    const int BQ = obs_bitmap_bytes(cfg.obs_bytes) / 16;
+    const int GW = cfg.GS / 4;  // <= 256 dwords: up to 4 passes of 64 lanes
+    const bool has_cells = obs && !(OBS_ABLATE & 4);
+    const uint32_t* slot_agents = slots.a;
+            // ---- zero the bitmap, park the record in LDS
+            if (obs) {
+                const u32x4_t z = {0u, 0u, 0u, 0u};
+                for (int q = lane; q < BQ; q += WAVE) ((u32x4_t*)bits)[q] = z;
+            }
+            if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
+            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- hot bits of every tile plane
+            if (has_cells) {
+                for (int w = lane; w < GW; w += WAVE) {
+                    if (w >= WAVE) cells = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16 only
+                    int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
+    #pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int cell = w * 4 + b;
+                        const uint32_t v = (cells >> (8 * b)) & 0xFFu;
+                        if (v != 0 && cell < GG) {
+                            const int fl = flip_cell(cfg, cell, r, c);
+    #pragma unroll
+                            for (int slot = 0; slot < 4; slot++) {
+                                if (slot_agents[slot]) {  // uniform
+                                    const uint32_t code = (uint32_t)(pin64(cfg.chan_lut[slot >> 1]) >> (4 * v)) & 15u;
+                                    if (code != CTF_TILE_NONE) {
+                                        const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
+                                        for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
+                                            const uint32_t bit = (uint32_t)(__ffs((int)m) - 1) * (uint32_t)cfg.CGG + q;
+                                            atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (++c == G) { c = 0; r++; }
+                    }
+                }
+            }
+            // ---- plane 0: the viewer's own position
+            if (obs && lane < N) {
+                const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
+                const int r = ps[2 * lane], c = ps[2 * lane + 1];
+                const int cell = ((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c;
+                const uint32_t bit = (uint32_t)lane * (uint32_t)cfg.CGG + (uint32_t)cell;
+                atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
+            }
+
+            // ---- metadata (gridworld_ctf.py:1027-1069).  A: the few distinct values, as f16 bits
+            if (meta && !(OBS_ABLATE & 8)) {
+                const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
+                if (lane < 36) {
+                    double val = 0.0;
+                    if (lane == 0) val = (double)misc[0] / (double)cfg.game_steps;
+                    else if (lane < 3) val = (double)(misc[lane] + 1) / (double)(misc[3 - lane] + 1);  // viewer team lane-1
+                    else if (lane >= 4 && lane < 4 + N) {
+                        // the quirk at :1039-1041: hp of the agent whose INDEX is type(j), over max hp of type(j), as uint8
+                        const int tv = cfg_type(cfg, lane - 4);
+                        double q = 0.0;
+                        if (tv < N) {
+                            const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
+                            q = __hiloint2double((int)hq[1], (int)hq[0]) / sel4(cfg.type_hp, tv);
+                        }
+                        val = (double)(uint8_t)(long long)q;
+                    } else if (lane >= 20 && lane < 20 + N) val = (double)srec[cfg.off_flag + lane - 20];
+                    mv[lane] = f64_to_f16(val);
+                }
+                __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+                __builtin_amdgcn_wave_barrier();
+                // B: every element of the N x M block is one of those values
+                for (int idx = lane; idx < N * M; idx += WAVE) {
+                    const int i = (int)fdiv((uint32_t)idx, cfg.div_m), k = idx - i * M;
+                    const int team = cfg_team(cfg, i);
+                    uint16_t hv = 0;
+                    if (k == 0) hv = mv[0];
+                    else if (k == 1) hv = mv[1 + team];
+                    else if (k < 6) hv = (k - 2 == cfg_type(cfg, i)) ? (uint16_t)0x3C00u : (uint16_t)0u;
+                    else {
+                        // rows 6,7: the agent itself; then own-team list minus self, then the opponents list (:1053-1067)
+                        int who = i;
+                        if (k >= 8) {
+                            const int pidx = (k - 8) >> 1;
+                            const int n_own = cfg_nopp(cfg, 1 - team), n_op = cfg_nopp(cfg, team);
+                            const int self_idx = (int)((pin64(cfg.self_idx_pack) >> (4 * i)) & 15u);
+                            const int n_mates = n_own - (self_idx < n_own ? 1 : 0);
+                            if (pidx < n_mates) who = cfg_opp(cfg, 1 - team, pidx + (pidx >= self_idx ? 1 : 0));
+                            else if (pidx - n_mates < n_op) who = cfg_opp(cfg, team, pidx - n_mates);
+                            else who = -1;
+                        }
+                        if (who >= 0) hv = mv[((k & 1) ? 20 : 4) + who];
+                    }
+                    mstage[idx] = hv;
+                }
+                __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+                __builtin_amdgcn_wave_barrier();
+                // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
+                u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
+                for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)mstage)[q];
+            }
+            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the bitmap's atomic ORs have landed
+            __builtin_amdgcn_wave_barrier();
+
+}
+
+// one 16-byte chunk of the observation block: halfword k of the bitmap, every bit expanded to a byte
+template <int ALIGN>
+__device__ __forceinline__ void obs_store_chunk(uint8_t* out, const uint16_t* hb, int k, int nfull, int tail, uint32_t& ablate_acc) {
+    const uint32_t o = (uint32_t)k << 4;
+    const uint32_t h = hb[k];
+    uint32_t x[4];
+    if (OBS_ABLATE & 1) { x[0] = x[1] = x[2] = x[3] = h; }
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = expand4(h, j);
+    }
+    if (OBS_ABLATE & 2) { ablate_acc ^= x[0] ^ x[1] ^ x[2] ^ x[3]; return; }
+    if (k < nfull) {
+        if (ALIGN >= 4) {
+            typedef typename OutVec<(ALIGN >= 16 ? 16 : 4)>::type V;
+            const V v = {x[0], x[1], x[2], x[3]};
+            *(V*)(out + o) = v;  // plain store: measured faster than nontemporal for this pattern
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) out[o + j] = (uint8_t)(x[j >> 2] >> ((j & 3) * 8));
+        }
+    } else {
+        for (int j = 0; j < tail; j++) out[o + j] = (uint8_t)(x[j >> 2] >> ((j & 3) * 8));
+    }
+}
+
+// Every wave builds and streams its own envs.  (A builder / streamer split — one wave of a block building the next
+// three envs' bitmaps while the other three stream — was tried and measured 15-25 % slower: a single builder wave's
+// dependent chain is too long, and 24 streaming waves per CU drive the store path less well than 32.)
 template <int ALIGN>
 __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs,
                                                  uint16_t* __restrict__ meta, uint32_t reverse_mask) {
@@ -824,25 +983,14 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const int wpb = blockDim.x / WAVE;
-    const int N = cfg.N, G = cfg.G, GG = cfg.GG, M = cfg.M;
+    const int N = cfg.N, M = cfg.M;
     uint8_t* wl = (uint8_t*)lds + wave * obs_wave_bytes(cfg.RS, N, M, cfg.obs_bytes);
     uint8_t* srec = wl;
     uint16_t* mv = (uint16_t*)(wl + cfg.RS);
     uint16_t* mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
     uint32_t* bits = (uint32_t*)(wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M));
-    const int BQ = obs_bitmap_bytes(cfg.obs_bytes) / 16;
-    // agents per (viewer team, reversed?) view slot — uniform over the launch
-    uint32_t slot_agents[4] = {0, 0, 0, 0};
-    for (int i = 0; i < N; i++) {
-        const int sl = cfg.team[i] * 2 + (int)((reverse_mask >> i) & 1u);
-        slot_agents[0] |= (sl == 0) ? (1u << i) : 0u;
-        slot_agents[1] |= (sl == 1) ? (1u << i) : 0u;
-        slot_agents[2] |= (sl == 2) ? (1u << i) : 0u;
-        slot_agents[3] |= (sl == 3) ? (1u << i) : 0u;
-    }
-
-    const bool has_cells = obs && !(OBS_ABLATE & 4);
-    const int GW = cfg.GS / 4;  // <= 256 dwords: up to 4 passes of 64 lanes
+    const ObsSlots slots = obs_slots(cfg, reverse_mask);
+    const int GW = cfg.GS / 4;
     const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
     const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
     // the first env's state: ordinary loads; every later env's state arrives through the prefetch below
@@ -853,106 +1001,7 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
     }
 
     for (int e = e_first; e < cfg.n_envs; e += e_stride) {
-        // ---- zero the bitmap, park the record in LDS
-        if (obs) {
-            const u32x4_t z = {0u, 0u, 0u, 0u};
-            for (int q = lane; q < BQ; q += WAVE) ((u32x4_t*)bits)[q] = z;
-        }
-        if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- hot bits of every tile plane
-        if (has_cells) {
-            for (int w = lane; w < GW; w += WAVE) {
-                if (w >= WAVE) cells = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16 only
-                int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int cell = w * 4 + b;
-                    const uint32_t v = (cells >> (8 * b)) & 0xFFu;
-                    if (v != 0 && cell < GG) {
-                        const int fl = flip_cell(cfg, cell, r, c);
-#pragma unroll
-                        for (int slot = 0; slot < 4; slot++) {
-                            if (slot_agents[slot]) {  // uniform
-                                const uint32_t code = (uint32_t)(pin64(cfg.chan_lut[slot >> 1]) >> (4 * v)) & 15u;
-                                if (code != CTF_TILE_NONE) {
-                                    const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
-                                    for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
-                                        const uint32_t bit = (uint32_t)(__ffs((int)m) - 1) * (uint32_t)cfg.CGG + q;
-                                        atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (++c == G) { c = 0; r++; }
-                }
-            }
-        }
-        // ---- plane 0: the viewer's own position
-        if (obs && lane < N) {
-            const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
-            const int r = ps[2 * lane], c = ps[2 * lane + 1];
-            const int cell = ((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c;
-            const uint32_t bit = (uint32_t)lane * (uint32_t)cfg.CGG + (uint32_t)cell;
-            atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
-        }
-
-        // ---- metadata (gridworld_ctf.py:1027-1069).  A: the few distinct values, as f16 bits
-        if (meta && !(OBS_ABLATE & 8)) {
-            const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
-            if (lane < 36) {
-                double val = 0.0;
-                if (lane == 0) val = (double)misc[0] / (double)cfg.game_steps;
-                else if (lane < 3) val = (double)(misc[lane] + 1) / (double)(misc[3 - lane] + 1);  // viewer team lane-1
-                else if (lane >= 4 && lane < 4 + N) {
-                    // the quirk at :1039-1041: hp of the agent whose INDEX is type(j), over max hp of type(j), as uint8
-                    const int tv = cfg_type(cfg, lane - 4);
-                    double q = 0.0;
-                    if (tv < N) {
-                        const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
-                        q = __hiloint2double((int)hq[1], (int)hq[0]) / sel4(cfg.type_hp, tv);
-                    }
-                    val = (double)(uint8_t)(long long)q;
-                } else if (lane >= 20 && lane < 20 + N) val = (double)srec[cfg.off_flag + lane - 20];
-                mv[lane] = f64_to_f16(val);
-            }
-            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-            __builtin_amdgcn_wave_barrier();
-            // B: every element of the N x M block is one of those values
-            for (int idx = lane; idx < N * M; idx += WAVE) {
-                const int i = (int)fdiv((uint32_t)idx, cfg.div_m), k = idx - i * M;
-                const int team = cfg_team(cfg, i);
-                uint16_t hv = 0;
-                if (k == 0) hv = mv[0];
-                else if (k == 1) hv = mv[1 + team];
-                else if (k < 6) hv = (k - 2 == cfg_type(cfg, i)) ? (uint16_t)0x3C00u : (uint16_t)0u;
-                else {
-                    // rows 6,7: the agent itself; then own-team list minus self, then the opponents list (:1053-1067)
-                    int who = i;
-                    if (k >= 8) {
-                        const int pidx = (k - 8) >> 1;
-                        const int n_own = cfg_nopp(cfg, 1 - team), n_op = cfg_nopp(cfg, team);
-                        const int self_idx = (int)((pin64(cfg.self_idx_pack) >> (4 * i)) & 15u);
-                        const int n_mates = n_own - (self_idx < n_own ? 1 : 0);
-                        if (pidx < n_mates) who = cfg_opp(cfg, 1 - team, pidx + (pidx >= self_idx ? 1 : 0));
-                        else if (pidx - n_mates < n_op) who = cfg_opp(cfg, team, pidx - n_mates);
-                        else who = -1;
-                    }
-                    if (who >= 0) hv = mv[((k & 1) ? 20 : 4) + who];
-                }
-                mstage[idx] = hv;
-            }
-            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-            __builtin_amdgcn_wave_barrier();
-            // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
-            u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
-            for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)mstage)[q];
-        }
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the bitmap's atomic ORs have landed
-        __builtin_amdgcn_wave_barrier();
+        obs_build_env(cfg, p, e, recw, cells, srec, mv, mstage, bits, slots, reverse_mask, lane, obs != nullptr, meta);
 
         // ---- stream the observation block: 16 bytes per lane per store.  Wave store instructions are
         // aligned to 1 KiB of the flat output (k starts negative), so only an env's first and last
@@ -977,27 +1026,7 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
                 if (OBS_PREFETCH && it == OBS_PF_WAIT) OBS_PREFETCH_WAIT(nrec, ncells);
                 const int k = k0 + lane + it * WAVE;
                 if (k < 0 || k >= nchunks) continue;
-                const uint32_t o = (uint32_t)k << 4;
-                const uint32_t h = hb[k];
-                uint32_t x[4];
-                if (OBS_ABLATE & 1) { x[0] = x[1] = x[2] = x[3] = h; }
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) x[j] = expand4(h, j);
-                }
-                if (OBS_ABLATE & 2) { ablate_acc ^= x[0] ^ x[1] ^ x[2] ^ x[3]; continue; }
-                if (k < nfull) {
-                    if (ALIGN >= 4) {
-                        typedef typename OutVec<(ALIGN >= 16 ? 16 : 4)>::type V;
-                        const V v = {x[0], x[1], x[2], x[3]};
-                        *(V*)(out + o) = v;  // plain store: measured faster than nontemporal for this pattern
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 16; j++) out[o + j] = (uint8_t)(x[j >> 2] >> ((j & 3) * 8));
-                    }
-                } else {
-                    for (int j = 0; j < tail; j++) out[o + j] = (uint8_t)(x[j >> 2] >> ((j & 3) * 8));
-                }
+                obs_store_chunk<ALIGN>(out, hb, k, nfull, tail, ablate_acc);
             }
             if ((OBS_ABLATE & 2) && ablate_acc == 0x12345678u) out[lane] = 1;  // keeps the ablated work alive
             if (OBS_PREFETCH) {
@@ -1099,6 +1128,8 @@ extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const
 }
 extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask,
                                          int n_cus, hipStream_t st) {
+    const uintptr_t a = (uintptr_t)obs;
+    const int align = ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0) ? 16 : (((cfg.obs_bytes % 4) == 0 && (a % 4) == 0) ? 4 : 1);
     // waves per block: 4 unless one env's bitmap is so large that 4 of them would crowd the CU's LDS
     const int per_wave = obs_wave_bytes(cfg.RS, cfg.N, cfg.M, cfg.obs_bytes);
     int wpb = 4;
@@ -1108,13 +1139,9 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     const int cap = n_cus * (32 / wpb);  // the CU's 32-wave limit; grid-stride beyond that
     if (blocks > cap) blocks = cap;
     const dim3 grid(blocks), block(wpb * WAVE);
-    const uintptr_t a = (uintptr_t)obs;
-    if ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0)
-        hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
-    else if ((cfg.obs_bytes % 4) == 0 && (a % 4) == 0)
-        hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
-    else
-        hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
+    if (align == 16) hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
+    else if (align == 4) hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
+    else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg& cfg, const DevPtrs& p, int32_t* metrics, int32_t* captures, int32_t* steps,
