@@ -66,3 +66,22 @@ def test_batched_duel_matches_reference_duel(name):
     v = vec.get_state(1)
     assert np.array_equal(out["metrics"][1].cpu().numpy(), np.array([[v.metrics[k][i] for i in range(vec.N_AGENTS)] for k in range(13)]))
     vec.close()
+
+
+def test_trajectory_export_matches_reference_duel_json():
+    """utils.duel_json (utils.py:728-815) on the reference env vs duel.duel_trajectory: the same record, key for key."""
+    import gzip
+
+    duel = importlib.import_module("marl-ctf-development_amd.duel")
+    with gzip.open(os.path.join(GOLDEN, "trajectory_arena.json.gz"), "rt") as f:
+        blob = json.load(f)
+    case, want = blob["case"], blob["record"]
+    kwargs = kwargs_from_json(case)
+    seed = case["seed"]
+    vec = pkg.VecGridworldCtf(2, device=0, py_seeds=[seed + 9, seed], np_seeds=[seed + 9, seed], **kwargs)
+    got = duel.duel_trajectory(vec, StubPolicy(case["salts"][0]), StubPolicy(case["salts"][1]), env_index=1, max_steps=case["max_steps"])
+    got = json.loads(json.dumps(got))  # plain JSON types, like the reference's file
+    assert sorted(got) == sorted(want)
+    for key in want:
+        assert got[key] == want[key], key
+    vec.close()
