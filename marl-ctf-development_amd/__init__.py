@@ -17,3 +17,11 @@ from .gridworld_ctf import GridworldCtf, VecGridworldCtf  # noqa: F401
 from .maps import CtfScenarios  # noqa: F401
 from .rollout import BatchedRolloutCollector  # noqa: F401
 from .duel import batched_duel  # noqa: F401
+
+
+def __getattr__(name):  # the policy module needs torch.nn: import it only when asked for
+    if name == "policy":
+        import importlib
+
+        return importlib.import_module(__name__ + ".policy")
+    raise AttributeError(name)
