@@ -92,7 +92,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # CTF_FORCE_DIST=1 runs the RCCL code path even with one rank (rehearsal of the N>1 path on a 1-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("CTF_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=device)
@@ -114,7 +116,7 @@ def main():
     actions = torch.empty((W + K, E, N), dtype=torch.int8, device=device)
     for t in range(W + K):
         vec.random_actions(actions[t], seed=0xC7F, step=t, env_offset=lo)
-    gather = sh.RolloutGather(vec.rewards, vec.done, world)
+    gather = sh.RolloutGather(vec.rewards, vec.done, world, force_collective=use_dist)
     vec.observe()
 
     def one_step(t, events=None):
@@ -123,16 +125,19 @@ def main():
         rewards, done = vec.step(actions[t], auto_reset=True)
         if events:
             events[1].record()
-        gather.start(rewards, done)  # async RCCL all-gather of the compact rollout tensors (copy at N=1)
         vec.observe()
         if events:
             events[2].record()
+        # async RCCL all-gather of the compact rollout tensors (a copy at N=1).  Issued AFTER the render so that it runs
+        # beside the next step kernel (which leaves half of the wave slots free) — beside the render, which fills every
+        # slot with equal-sized shares of work, it delayed a few blocks and stretched the kernel by 15 %
+        gather.start(rewards, done)
 
     for t in range(W):
         one_step(t)
     gather.wait()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -140,10 +145,10 @@ def main():
         one_step(W + t, ev[t])
     gather.wait()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = sh.max_over_ranks(elapsed, device, world)
+    elapsed = sh.max_over_ranks(elapsed, device, world if not use_dist else max(world, 2))
     status = vec.status()
 
     step_all = np.array([e[0].elapsed_time(e[1]) for e in ev])
@@ -176,7 +181,7 @@ def main():
                 "envs_per_gpu": E,
                 "global_envs": n_gpus * E,
                 "metrics_counters": not args.no_metrics,
-                "rollout_exchange": "RCCL all-gather of rewards+done per step, async" if world > 1 else "none (1 GPU)",
+                "rollout_exchange": "RCCL all-gather of rewards+done per step, async" if use_dist else "none (1 GPU)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -199,7 +204,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pkg, kwargs)
         print(json.dumps(line), flush=True)
     vec.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -9,6 +9,8 @@
 // Integer / byte work, HBM-bound: no MFMA anywhere.  Wavefront = 64 lanes is assumed throughout.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ctf_device.h"
 
 #define WAVE 64
@@ -1126,6 +1128,10 @@ extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const
     else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, st);
     return hipGetLastError();
 }
+static int obs_reserve_blocks() {
+    static const int v = [] { const char* e = getenv("CTF_OBS_RESERVE_BLOCKS"); return e ? atoi(e) : 0; }();
+    return v < 0 ? 0 : v;
+}
 extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask,
                                          int n_cus, hipStream_t st) {
     const uintptr_t a = (uintptr_t)obs;
@@ -1136,7 +1142,10 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     while (wpb > 1 && wpb * per_wave > 40 * 1024) wpb >>= 1;
     const size_t sh = (size_t)wpb * per_wave;
     int blocks = (cfg.n_envs + wpb - 1) / wpb;
-    const int cap = n_cus * (32 / wpb);  // the CU's 32-wave limit; grid-stride beyond that
+    // the CU's 32-wave limit, grid-stride beyond that; a few block slots stay free so that a concurrent small kernel
+    // (the RCCL all-gather of the rollout tensors) can start beside this launch instead of behind it
+    int cap = n_cus * (32 / wpb);
+    if (cap > 64) cap -= obs_reserve_blocks();
     if (blocks > cap) blocks = cap;
     const dim3 grid(blocks), block(wpb * WAVE);
     if (align == 16) hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);

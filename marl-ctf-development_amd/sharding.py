@@ -32,10 +32,11 @@ class RolloutGather:
     """All-gather of the per-step compact rollout tensors (rewards [E, N] f32, done [E] u8) of every
     shard, double-buffered so that the collective of step t may still be in flight while step t+1 runs."""
 
-    def __init__(self, rewards, done, world, group=None):
+    def __init__(self, rewards, done, world, group=None, force_collective=False):
         import torch
 
         self.world, self.group = world, group
+        self.collective = world > 1 or force_collective
         self.bufs, self.src = [], []
         for _ in range(2):
             self.bufs.append((
@@ -55,7 +56,7 @@ class RolloutGather:
         slot = self.k & 1
         self.wait(slot)
         gr, gd = self.bufs[slot]
-        if self.world == 1:
+        if not self.collective:
             gr.copy_(rewards, non_blocking=True)
             gd.copy_(done, non_blocking=True)
         else:
