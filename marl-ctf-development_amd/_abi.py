@@ -150,8 +150,15 @@ def load_library(path=None):
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch-less callers use /opt/rocm's runtime
         pass
+    lib = bind(path)
+    _lib = lib
+    return lib
+
+
+def bind(path, mode=C.RTLD_GLOBAL):
+    """dlopen one build of the library and type its entry points (tools/ab_inproc.py loads several side by side)."""
     try:
-        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(path, mode=mode)
     except OSError as exc:
         raise CtfLibraryError(f"cannot load {path}: {exc}") from exc
     for name, (restype, argtypes) in SYMBOLS.items():
@@ -165,7 +172,6 @@ def load_library(path=None):
         raise CtfLibraryError(f"ABI version mismatch: library {lib.ctf_abi_version()} != binding {ABI_VERSION}")
     if lib.ctf_sizeof_config() != C.sizeof(CtfConfig) or lib.ctf_sizeof_state_view() != C.sizeof(CtfStateView):
         raise CtfLibraryError("struct layout mismatch between include/ctf_env.h and the ctypes mirror")
-    _lib = lib
     return lib
 
 

@@ -809,7 +809,10 @@ __device__ __forceinline__ uint32_t obs_prefetch_dword(const uint32_t* ptr) {
 #ifndef OBS_PREFETCH
 #define OBS_PREFETCH 1  // 0 = profiling comparison only (tools/ablate.sh)
 #endif
-#define OBS_PF_WAIT 10  // stream iteration at which the prefetched state is waited for ...
+#ifndef OBS_UNROLL
+#define OBS_UNROLL 4    // store instructions per pass of the stream loop
+#endif
+#define OBS_PF_WAIT 12  // stream iteration (a multiple of OBS_UNROLL) at which the prefetched state is waited for ...
 // ... with vmcnt(8): the two prefetch loads are older than the >= OBS_PF_WAIT stores issued since
 #define OBS_PREFETCH_WAIT(a, b) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a), "+v"(b)::"memory")
 #define OBS_PREFETCH_DRAIN(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory")
@@ -949,11 +952,10 @@ __device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& 
 
 }
 
-// one 16-byte chunk of the observation block: halfword k of the bitmap, every bit expanded to a byte
+// one 16-byte chunk of the observation block: h = halfword k of the bitmap, every bit expanded to a byte
 template <int ALIGN>
-__device__ __forceinline__ void obs_store_chunk(uint8_t* out, const uint16_t* hb, int k, int nfull, int tail, uint32_t& ablate_acc) {
+__device__ __forceinline__ void obs_store_chunk(uint8_t* out, uint32_t h, int k, int nfull, int tail, uint32_t& ablate_acc) {
     const uint32_t o = (uint32_t)k << 4;
-    const uint32_t h = hb[k];
     uint32_t x[4];
     if (OBS_ABLATE & 1) { x[0] = x[1] = x[2] = x[3] = h; }
     else {
@@ -1020,15 +1022,25 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
             const int niter = (nchunks - k0 + WAVE - 1) / WAVE;
             const int e_next = min(e + e_stride, cfg.n_envs - 1);
             uint32_t nrec = 0, ncells = 0;
-            for (int it = 0; it < niter; it++) {
-                if (OBS_PREFETCH && it == 0) {  // next env's state: issued before this env's first store
+            // OBS_UNROLL store instructions per pass, their bitmap halfwords read first: the stores then issue back to back
+            // instead of each waiting for its own LDS round trip
+            for (int it0 = 0; it0 < niter; it0 += OBS_UNROLL) {
+                if (OBS_PREFETCH && it0 == 0) {  // next env's state: issued before this env's first store
                     nrec = obs_prefetch_dword((const uint32_t*)(p.rec + (size_t)e_next * cfg.RS) + rec_lane);
                     ncells = obs_prefetch_dword((const uint32_t*)(p.grid + (size_t)e_next * cfg.GS) + grid_lane);
                 }
-                if (OBS_PREFETCH && it == OBS_PF_WAIT) OBS_PREFETCH_WAIT(nrec, ncells);
-                const int k = k0 + lane + it * WAVE;
-                if (k < 0 || k >= nchunks) continue;
-                obs_store_chunk<ALIGN>(out, hb, k, nfull, tail, ablate_acc);
+                if (OBS_PREFETCH && it0 == OBS_PF_WAIT) OBS_PREFETCH_WAIT(nrec, ncells);
+                uint32_t h[OBS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < OBS_UNROLL; u++) {
+                    const int k = k0 + lane + (it0 + u) * WAVE;
+                    h[u] = (k >= 0 && k < nchunks) ? hb[k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < OBS_UNROLL; u++) {
+                    const int k = k0 + lane + (it0 + u) * WAVE;
+                    if (k >= 0 && k < nchunks) obs_store_chunk<ALIGN>(out, h[u], k, nfull, tail, ablate_acc);
+                }
             }
             if ((OBS_ABLATE & 2) && ablate_acc == 0x12345678u) out[lane] = 1;  // keeps the ablated work alive
             if (OBS_PREFETCH) {

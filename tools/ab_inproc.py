@@ -1,0 +1,39 @@
+"""A/B of several builds of the library IN ONE PROCESS on the SAME output buffers (placement of a large allocation
+alone moves the render by 20 %, so separate processes cannot be compared).  Usage (GPU box):
+    python tools/ab_inproc.py "<hipcc -D flags of build A>" "<flags of build B>" ...
+"""
+import ctypes, importlib, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+pkg = importlib.import_module("marl-ctf-development_amd")
+abi = pkg._abi
+CS = os.path.join(ROOT, "marl-ctf-development_amd", "csrc")
+OUT = os.path.join(ROOT, "gpurun_out", "ab")
+os.makedirs(OUT, exist_ok=True)
+E = int(os.environ.get("AB_ENVS", 65536))
+kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+vecs = []
+for i, flags in enumerate(sys.argv[1:]):
+    so = os.path.join(OUT, f"lib{i}.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic"]
+                          + flags.split() + ["-shared", "-o", so, os.path.join(CS, "ctf_abi.hip"), os.path.join(CS, "ctf_kernels.hip")])
+    vecs.append((flags, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL), **kw)))
+shared_obs, shared_meta = vecs[0][1].obs, vecs[0][1].meta
+acts = torch.zeros((E, 8), dtype=torch.int8, device="cuda")
+vecs[0][1].random_actions(acts, seed=5, step=0)
+res = {f: ([], []) for f, _ in vecs}
+for rnd in range(4):
+    for flags, v in vecs:
+        v.obs, v.meta = shared_obs, shared_meta
+        for _ in range(10):
+            v.step(acts, auto_reset=True); v.observe()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(60)]
+        for a, b, c in ev:
+            a.record(); v.step(acts, auto_reset=True); b.record(); v.observe(); c.record()
+        torch.cuda.synchronize()
+        if rnd:
+            res[flags][0].append(np.median([a.elapsed_time(b) for a, b, c in ev]))
+            res[flags][1].append(np.median([b.elapsed_time(c) for a, b, c in ev]))
+for flags, (st, ob) in res.items():
+    print(f"[{flags or 'default'}] step {np.mean(st):.4f} ms  observe {np.mean(ob):.4f} ms  (rounds: {', '.join('%.4f' % x for x in ob)})", flush=True)
