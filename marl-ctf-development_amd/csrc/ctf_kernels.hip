@@ -775,7 +775,7 @@ __host__ __device__ inline int obs_wave_bytes(int RS, int N, int M, int obs_byte
 
 #define LGKM_ONLY 0xC07F  // s_waitcnt lgkmcnt(0): LDS traffic only — never drain the wave's outstanding stores
 // Profiling-only ablations (never defined in the shipped build; see tools/ablate.sh):
-//   bit0 no bit expansion, bit1 no chunk stores, bit2 no bitmap build, bit3 no metadata
+//   bit0 no bit expansion, bit1 no chunk stores, bit2 no bitmap build, bit3 no metadata, bit4 metadata computed but not stored
 #ifndef OBS_ABLATE
 #define OBS_ABLATE 0
 #endif
@@ -945,6 +945,7 @@ __device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& 
                 __builtin_amdgcn_wave_barrier();
                 // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
                 u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
+                if (!(OBS_ABLATE & 16))
                 for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)mstage)[q];
             }
             __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the bitmap's atomic ORs have landed

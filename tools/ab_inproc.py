@@ -35,5 +35,10 @@ for rnd in range(4):
         if rnd:
             res[flags][0].append(np.median([a.elapsed_time(b) for a, b, c in ev]))
             res[flags][1].append(np.median([b.elapsed_time(c) for a, b, c in ev]))
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+for a, b in ev:
+    a.record(); shared_obs.fill_(1); b.record()
+torch.cuda.synchronize()
+print("reference: torch fill_ of the same buffer %.4f ms" % np.median([a.elapsed_time(b) for a, b in ev]), flush=True)
 for flags, (st, ob) in res.items():
     print(f"[{flags or 'default'}] step {np.mean(st):.4f} ms  observe {np.mean(ob):.4f} ms  (rounds: {', '.join('%.4f' % x for x in ob)})", flush=True)
