@@ -998,14 +998,15 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
     const int GW = cfg.GS / 4;
     const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
     const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
+    const int e_end = cfg.n_envs;
     // the first env's state: ordinary loads; every later env's state arrives through the prefetch below
     uint32_t recw = 0, cells = 0;
-    if (e_first < cfg.n_envs) {
+    if (e_first < e_end) {
         recw = ((const uint32_t*)(p.rec + (size_t)e_first * cfg.RS))[rec_lane];
         cells = ((const uint32_t*)(p.grid + (size_t)e_first * cfg.GS))[grid_lane];
     }
 
-    for (int e = e_first; e < cfg.n_envs; e += e_stride) {
+    for (int e = e_first; e < e_end; e += e_stride) {
         obs_build_env(cfg, p, e, recw, cells, srec, mv, mstage, bits, slots, reverse_mask, lane, obs != nullptr, meta);
 
         // ---- stream the observation block: 16 bytes per lane per store.  Wave store instructions are
@@ -1021,7 +1022,7 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
             const int k0 = (ALIGN >= 16) ? -(int)(((base + (uintptr_t)obs) >> 4) & 63) : 0;
             uint32_t ablate_acc = 0;
             const int niter = (nchunks - k0 + WAVE - 1) / WAVE;
-            const int e_next = min(e + e_stride, cfg.n_envs - 1);
+            const int e_next = min(e + e_stride, e_end - 1);
             uint32_t nrec = 0, ncells = 0;
             // OBS_UNROLL store instructions per pass, their bitmap halfwords read first: the stores then issue back to back
             // instead of each waiting for its own LDS round trip
@@ -1048,11 +1049,11 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
                 if (niter <= OBS_PF_WAIT) OBS_PREFETCH_DRAIN(nrec, ncells);
                 recw = nrec;
                 cells = ncells;
-            } else if (e + e_stride < cfg.n_envs) {
+            } else if (e + e_stride < e_end) {
                 recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
                 cells = ((const uint32_t*)(p.grid + (size_t)(e + e_stride) * cfg.GS))[grid_lane];
             }
-        } else if (e + e_stride < cfg.n_envs) {
+        } else if (e + e_stride < e_end) {
             recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
         }
         __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // this env's LDS reads are done before the next env reuses the bitmap
