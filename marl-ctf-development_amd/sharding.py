@@ -57,8 +57,7 @@ class RolloutGather:
         self.wait(slot)
         gr, gd = self.bufs[slot]
         if not self.collective:
-            gr.copy_(rewards, non_blocking=True)
-            gd.copy_(done, non_blocking=True)
+            self.bufs[slot] = (rewards, done)  # one rank: the shard is the whole batch, nothing to exchange or copy
         else:
             sr, sd = self.src[slot]
             sr.copy_(rewards, non_blocking=True)
