@@ -765,12 +765,13 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
 //      instruction per 64 chunks.
 // Metadata rows (f16 [N][2N+6]) are assembled in LDS and leave as 8-byte stores.
 //
-// Per-wave LDS (bytes): [rec RS][mvals 96][meta staging][bitmap]
+// Per-wave LDS (bytes): [rec RS][mvals 96][meta staging][meta source LUT][bitmap]
 #define OBS_MV_BYTES 96
 __host__ __device__ inline int obs_meta_stage_bytes(int N, int M) { return (N * M * 2 + 15) & ~15; }
 __host__ __device__ inline int obs_bitmap_bytes(int obs_bytes) { return ((((obs_bytes + 31) / 32 + 1) * 4) + 15) & ~15; }
+__host__ __device__ inline int obs_meta_lut_bytes(int N, int M) { return (N * M + 15) & ~15; }
 __host__ __device__ inline int obs_wave_bytes(int RS, int N, int M, int obs_bytes) {
-    return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_bitmap_bytes(obs_bytes);
+    return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_meta_lut_bytes(N, M) + obs_bitmap_bytes(obs_bytes);
 }
 
 #define LGKM_ONLY 0xC07F  // s_waitcnt lgkmcnt(0): LDS traffic only — never drain the wave's outstanding stores
@@ -837,11 +838,42 @@ __device__ __forceinline__ ObsSlots obs_slots(const DevCfg& cfg, uint32_t revers
     return s;
 }
 
+// Which of the (at most 36 distinct + two constant) values mv[] each element of the N x M metadata block shows
+// (gridworld_ctf.py:1044-1067): mv[0] step fraction, mv[1 + t] capture ratio for a viewer of team t, mv[4 + j] the
+// uint8-truncated hp of agent j, mv[20 + j] has_flag[j], mv[40] = 1.0, mv[41] = 0.0.
+__device__ __forceinline__ void obs_meta_lut(const DevCfg& cfg, uint8_t* mlut, uint16_t* mv, int lane) {
+    const int N = cfg.N, M = cfg.M;
+    for (int idx = lane; idx < N * M; idx += WAVE) {
+        const int i = (int)fdiv((uint32_t)idx, cfg.div_m), k = idx - i * M;
+        const int team = cfg_team(cfg, i);
+        int src = 41;
+        if (k == 0) src = 0;
+        else if (k == 1) src = 1 + team;
+        else if (k < 6) src = (k - 2 == cfg_type(cfg, i)) ? 40 : 41;
+        else {
+            // rows 6,7: the agent itself; then own-team list minus self, then the opponents list (:1053-1067)
+            int who = i;
+            if (k >= 8) {
+                const int pidx = (k - 8) >> 1;
+                const int n_own = cfg_nopp(cfg, 1 - team), n_op = cfg_nopp(cfg, team);
+                const int self_idx = (int)((pin64(cfg.self_idx_pack) >> (4 * i)) & 15u);
+                const int n_mates = n_own - (self_idx < n_own ? 1 : 0);
+                if (pidx < n_mates) who = cfg_opp(cfg, 1 - team, pidx + (pidx >= self_idx ? 1 : 0));
+                else if (pidx - n_mates < n_op) who = cfg_opp(cfg, team, pidx - n_mates);
+                else who = -1;
+            }
+            if (who >= 0) src = ((k & 1) ? 20 : 4) + who;
+        }
+        mlut[idx] = (uint8_t)src;
+    }
+    if (lane == 0) { mv[40] = 0x3C00u; mv[41] = 0u; }
+}
+
 // Everything of one env except the streaming: bitmap (zero + hot bits + own-position bits) into `bits`, metadata rows
 // to global memory.  `recw` / `cells` are the lane's dword of the env's record / grid (lane-clamped loads).
 // srec / mv / mstage are the calling wave's scratch.  Ends with the wave's LDS traffic drained.
 __device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& p, int e, uint32_t recw, uint32_t cells,
-                                              uint8_t* srec, uint16_t* mv, uint16_t* mstage, uint32_t* bits,
+                                              uint8_t* srec, uint16_t* mv, uint16_t* mstage, const uint8_t* mlut, uint32_t* bits,
                                               const ObsSlots& slots, uint32_t reverse_mask, int lane, bool obs,
                                               uint16_t* __restrict__ meta) {
     const int N = cfg.N, G = cfg.G, GG = cfg.GG, M = cfg.M;
@@ -849,107 +881,85 @@ __device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& 
     const int GW = cfg.GS / 4;  // <= 256 dwords: up to 4 passes of 64 lanes
     const bool has_cells = obs && !(OBS_ABLATE & 4);
     const uint32_t* slot_agents = slots.a;
-            // ---- zero the bitmap, park the record in LDS
-            if (obs) {
-                const u32x4_t z = {0u, 0u, 0u, 0u};
-                for (int q = lane; q < BQ; q += WAVE) ((u32x4_t*)bits)[q] = z;
-            }
-            if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
-            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-            __builtin_amdgcn_wave_barrier();
+    // ---- zero the bitmap, park the record in LDS
+    if (obs) {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        for (int q = lane; q < BQ; q += WAVE) ((u32x4_t*)bits)[q] = z;
+    }
+    if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
+    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+    __builtin_amdgcn_wave_barrier();
 
-            // ---- hot bits of every tile plane
-            if (has_cells) {
-                for (int w = lane; w < GW; w += WAVE) {
-                    if (w >= WAVE) cells = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16 only
-                    int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
-    #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const int cell = w * 4 + b;
-                        const uint32_t v = (cells >> (8 * b)) & 0xFFu;
-                        if (v != 0 && cell < GG) {
-                            const int fl = flip_cell(cfg, cell, r, c);
-    #pragma unroll
-                            for (int slot = 0; slot < 4; slot++) {
-                                if (slot_agents[slot]) {  // uniform
-                                    const uint32_t code = (uint32_t)(pin64(cfg.chan_lut[slot >> 1]) >> (4 * v)) & 15u;
-                                    if (code != CTF_TILE_NONE) {
-                                        const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
-                                        for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
-                                            const uint32_t bit = (uint32_t)(__ffs((int)m) - 1) * (uint32_t)cfg.CGG + q;
-                                            atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
-                                        }
-                                    }
+    // ---- hot bits of every tile plane
+    if (has_cells) {
+        for (int w = lane; w < GW; w += WAVE) {
+            if (w >= WAVE) cells = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16 only
+            int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
+            #pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int cell = w * 4 + b;
+                const uint32_t v = (cells >> (8 * b)) & 0xFFu;
+                if (v != 0 && cell < GG) {
+                    const int fl = flip_cell(cfg, cell, r, c);
+                    #pragma unroll
+                    for (int slot = 0; slot < 4; slot++) {
+                        if (slot_agents[slot]) {  // uniform
+                            const uint32_t code = (uint32_t)(pin64(cfg.chan_lut[slot >> 1]) >> (4 * v)) & 15u;
+                            if (code != CTF_TILE_NONE) {
+                                const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
+                                for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
+                                    const uint32_t bit = (uint32_t)(__ffs((int)m) - 1) * (uint32_t)cfg.CGG + q;
+                                    atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
                                 }
                             }
                         }
-                        if (++c == G) { c = 0; r++; }
                     }
                 }
+                if (++c == G) { c = 0; r++; }
             }
-            // ---- plane 0: the viewer's own position
-            if (obs && lane < N) {
-                const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
-                const int r = ps[2 * lane], c = ps[2 * lane + 1];
-                const int cell = ((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c;
-                const uint32_t bit = (uint32_t)lane * (uint32_t)cfg.CGG + (uint32_t)cell;
-                atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
-            }
+        }
+    }
+    // ---- plane 0: the viewer's own position
+    if (obs && lane < N) {
+        const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
+        const int r = ps[2 * lane], c = ps[2 * lane + 1];
+        const int cell = ((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c;
+        const uint32_t bit = (uint32_t)lane * (uint32_t)cfg.CGG + (uint32_t)cell;
+        atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
+    }
 
-            // ---- metadata (gridworld_ctf.py:1027-1069).  A: the few distinct values, as f16 bits
-            if (meta && !(OBS_ABLATE & 8)) {
-                const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
-                if (lane < 36) {
-                    double val = 0.0;
-                    if (lane == 0) val = (double)misc[0] / (double)cfg.game_steps;
-                    else if (lane < 3) val = (double)(misc[lane] + 1) / (double)(misc[3 - lane] + 1);  // viewer team lane-1
-                    else if (lane >= 4 && lane < 4 + N) {
-                        // the quirk at :1039-1041: hp of the agent whose INDEX is type(j), over max hp of type(j), as uint8
-                        const int tv = cfg_type(cfg, lane - 4);
-                        double q = 0.0;
-                        if (tv < N) {
-                            const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
-                            q = __hiloint2double((int)hq[1], (int)hq[0]) / sel4(cfg.type_hp, tv);
-                        }
-                        val = (double)(uint8_t)(long long)q;
-                    } else if (lane >= 20 && lane < 20 + N) val = (double)srec[cfg.off_flag + lane - 20];
-                    mv[lane] = f64_to_f16(val);
+    // ---- metadata (gridworld_ctf.py:1027-1069).  A: the few distinct values, as f16 bits
+    if (meta && !(OBS_ABLATE & 8)) {
+        const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
+        if (lane < 36) {
+            double val = 0.0;
+            if (lane == 0) val = (double)misc[0] / (double)cfg.game_steps;
+            else if (lane < 3) val = (double)(misc[lane] + 1) / (double)(misc[3 - lane] + 1);  // viewer team lane-1
+            else if (lane >= 4 && lane < 4 + N) {
+                // the quirk at :1039-1041: hp of the agent whose INDEX is type(j), over max hp of type(j), as uint8
+                const int tv = cfg_type(cfg, lane - 4);
+                double q = 0.0;
+                if (tv < N) {
+                    const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
+                    q = __hiloint2double((int)hq[1], (int)hq[0]) / sel4(cfg.type_hp, tv);
                 }
-                __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-                __builtin_amdgcn_wave_barrier();
-                // B: every element of the N x M block is one of those values
-                for (int idx = lane; idx < N * M; idx += WAVE) {
-                    const int i = (int)fdiv((uint32_t)idx, cfg.div_m), k = idx - i * M;
-                    const int team = cfg_team(cfg, i);
-                    uint16_t hv = 0;
-                    if (k == 0) hv = mv[0];
-                    else if (k == 1) hv = mv[1 + team];
-                    else if (k < 6) hv = (k - 2 == cfg_type(cfg, i)) ? (uint16_t)0x3C00u : (uint16_t)0u;
-                    else {
-                        // rows 6,7: the agent itself; then own-team list minus self, then the opponents list (:1053-1067)
-                        int who = i;
-                        if (k >= 8) {
-                            const int pidx = (k - 8) >> 1;
-                            const int n_own = cfg_nopp(cfg, 1 - team), n_op = cfg_nopp(cfg, team);
-                            const int self_idx = (int)((pin64(cfg.self_idx_pack) >> (4 * i)) & 15u);
-                            const int n_mates = n_own - (self_idx < n_own ? 1 : 0);
-                            if (pidx < n_mates) who = cfg_opp(cfg, 1 - team, pidx + (pidx >= self_idx ? 1 : 0));
-                            else if (pidx - n_mates < n_op) who = cfg_opp(cfg, team, pidx - n_mates);
-                            else who = -1;
-                        }
-                        if (who >= 0) hv = mv[((k & 1) ? 20 : 4) + who];
-                    }
-                    mstage[idx] = hv;
-                }
-                __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-                __builtin_amdgcn_wave_barrier();
-                // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
-                u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
-                if (!(OBS_ABLATE & 16))
-                for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)mstage)[q];
-            }
-            __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the bitmap's atomic ORs have landed
-            __builtin_amdgcn_wave_barrier();
+                val = (double)(uint8_t)(long long)q;
+            } else if (lane >= 20 && lane < 20 + N) val = (double)srec[cfg.off_flag + lane - 20];
+            mv[lane] = f64_to_f16(val);
+        }
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+        __builtin_amdgcn_wave_barrier();
+        // B: every element of the N x M block is one of those values (which one: obs_meta_lut, built once per wave)
+        for (int idx = lane; idx < N * M; idx += WAVE) mstage[idx] = mv[mlut[idx]];
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+        __builtin_amdgcn_wave_barrier();
+        // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
+        u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
+        if (!(OBS_ABLATE & 16))
+        for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)mstage)[q];
+    }
+    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the bitmap's atomic ORs have landed
+    __builtin_amdgcn_wave_barrier();
 
 }
 
@@ -993,8 +1003,10 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
     uint8_t* srec = wl;
     uint16_t* mv = (uint16_t*)(wl + cfg.RS);
     uint16_t* mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
-    uint32_t* bits = (uint32_t*)(wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M));
+    uint8_t* mlut = wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
+    uint32_t* bits = (uint32_t*)(mlut + obs_meta_lut_bytes(N, M));
     const ObsSlots slots = obs_slots(cfg, reverse_mask);
+    if (meta) obs_meta_lut(cfg, mlut, mv, lane);
     const int GW = cfg.GS / 4;
     const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
     const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
@@ -1007,7 +1019,7 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
     }
 
     for (int e = e_first; e < e_end; e += e_stride) {
-        obs_build_env(cfg, p, e, recw, cells, srec, mv, mstage, bits, slots, reverse_mask, lane, obs != nullptr, meta);
+        obs_build_env(cfg, p, e, recw, cells, srec, mv, mstage, mlut, bits, slots, reverse_mask, lane, obs != nullptr, meta);
 
         // ---- stream the observation block: 16 bytes per lane per store.  Wave store instructions are
         // aligned to 1 KiB of the flat output (k starts negative), so only an env's first and last

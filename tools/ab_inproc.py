@@ -16,8 +16,15 @@ kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
 vecs = []
 for i, flags in enumerate(sys.argv[1:]):
     so = os.path.join(OUT, f"lib{i}.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic"]
-                          + flags.split() + ["-shared", "-o", so, os.path.join(CS, "ctf_abi.hip"), os.path.join(CS, "ctf_kernels.hip")])
+    src = CS
+    if flags.startswith("@"):  # "@dir [flags]": build another copy of csrc (e.g. tools/_prev_csrc = the previous commit)
+        src, _, flags_only = flags[1:].partition(" ")
+        src = os.path.join(ROOT, src)
+    else:
+        flags_only = flags
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic",
+                           "-I" + os.path.join(ROOT, "marl-ctf-development_amd", "csrc")]
+                          + flags_only.split() + ["-shared", "-o", so, os.path.join(src, "ctf_abi.hip"), os.path.join(src, "ctf_kernels.hip")])
     vecs.append((flags, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL), **kw)))
 shared_obs, shared_meta = vecs[0][1].obs, vecs[0][1].meta
 acts = torch.zeros((E, 8), dtype=torch.int8, device="cuda")
