@@ -197,7 +197,9 @@ __device__ __forceinline__ double sel4(const double* t, int k) {
 // LDS slot of one env (bytes):
 //   [grid GS][rec RS][actions 16][py window 64][np window 64][metric deltas u8 13*N (METRICS)]
 // The slot stride in dwords is odd so that different groups' same-offset accesses fall in distinct banks.
+#ifndef WCAP
 #define WCAP 16  // MT words per window (>= 2 * max opponents per team)
+#endif
 // Profiling-only ablations of the step kernel (results become wrong; never defined in the shipped build):
 //   bit0 no tagging, bit1 no metric section, bit2 no shuffles, bit3 no act, bit4 no visitation atomics,
 //   bit5 no metric flush, bit6 no state write-back
@@ -811,9 +813,9 @@ __device__ __forceinline__ uint32_t obs_prefetch_dword(const uint32_t* ptr) {
 #define OBS_PREFETCH 1  // 0 = profiling comparison only (tools/ablate.sh)
 #endif
 #ifndef OBS_UNROLL
-#define OBS_UNROLL 4    // store instructions per pass of the stream loop
+#define OBS_UNROLL 8    // store instructions per pass of the stream loop
 #endif
-#define OBS_PF_WAIT 12  // stream iteration (a multiple of OBS_UNROLL) at which the prefetched state is waited for ...
+#define OBS_PF_WAIT 16  // stream iteration (a multiple of OBS_UNROLL) at which the prefetched state is waited for ...
 // ... with vmcnt(8): the two prefetch loads are older than the >= OBS_PF_WAIT stores issued since
 #define OBS_PREFETCH_WAIT(a, b) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a), "+v"(b)::"memory")
 #define OBS_PREFETCH_DRAIN(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory")
@@ -904,7 +906,9 @@ __device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& 
                     #pragma unroll
                     for (int slot = 0; slot < 4; slot++) {
                         if (slot_agents[slot]) {  // uniform
-                            const uint32_t code = (uint32_t)(pin64(cfg.chan_lut[slot >> 1]) >> (4 * v)) & 15u;
+                            // nibble v of the 64-bit LUT with 32-bit ops (a 64-bit variable shift is several times slower)
+                            const uint64_t lut = pin64(cfg.chan_lut[slot >> 1]);
+                            const uint32_t code = (((v & 8u) ? (uint32_t)(lut >> 32) : (uint32_t)lut) >> (4 * (v & 7u))) & 15u;
                             if (code != CTF_TILE_NONE) {
                                 const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
                                 for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
