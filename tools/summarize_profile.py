@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense one tools/profile.sh output directory into the files kept under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/prof_<tag> <round-tag> [workload-key]
+
+writes profiles/<round-tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, our kernels first),
+profiles/<round-tag>_pmc_summary.json (per-kernel mean of every counter of every --pmc pass, with the mean launch
+duration of that pass beside it) and updates profiles/traffic.json (HBM bytes per k_observe launch = WRITE_SIZE +
+2 x FETCH_SIZE, KiB units, the gfx950 correction of MI355X_MICROARCH.md) which bench.py reads for roofline.traffic.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def one(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    return hits[0] if hits else None
+
+
+def is_ours(name):
+    return name.startswith("void k_") or name.startswith("k_")
+
+
+def pmc_pass(path, tag, out):
+    # rows: one per (dispatch, counter)
+    vals = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(dict)
+    launch = {}
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            k = r["Kernel_Name"]
+            if not is_ours(k):
+                continue
+            vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            launch[k] = dict(vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"], grid=r["Grid_Size"],
+                             wg=r["Workgroup_Size"])
+    for k, cs in vals.items():
+        d = out.setdefault(k, {})
+        d["launch"] = launch[k]
+        for c, v in cs.items():
+            d[c] = sum(v) / len(v)
+        d["duration_ns@" + tag] = sum(dur[k].values()) / len(dur[k])
+        d["launches@" + tag] = len(dur[k])
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    key = sys.argv[3] if len(sys.argv) > 3 else "arena_65536"
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    stats = one(os.path.join(src, "trace", "**", "*_kernel_stats.csv"))
+    if stats:
+        rows = list(csv.reader(open(stats, newline="")))
+        head, body = rows[0], rows[1:]
+        body.sort(key=lambda r: (not is_ours(r[0]),))  # stable: ours first, rocprofv3's order (by total time) inside
+        with open(os.path.join(root, tag + "_kernel_stats.csv"), "w", newline="") as f:
+            csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows([head] + body)
+    out = {}
+    for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+        path = one(os.path.join(src, p, "**", "*_counter_collection.csv"))
+        if path:
+            pmc_pass(path, p, out)
+    json.dump(out, open(os.path.join(root, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    obs = next((v for k, v in out.items() if "k_observe" in k and "WRITE_SIZE" in v and "FETCH_SIZE" in v), None)
+    if obs:
+        tpath = os.path.join(root, "traffic.json")
+        traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        w, r = obs["WRITE_SIZE"] * 1024.0, obs["FETCH_SIZE"] * 1024.0 * 2.0
+        traffic[key] = {
+            "k_observe_hbm_bytes_per_launch": w + r, "write_bytes": w, "fetch_bytes_corrected_x2": r, "source": tag,
+            "note": "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate passes (tools/profile.sh), KiB units x1024; "
+                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read; our "
+                    "reads are 4 B/lane so the read side, 1% of the total, is approximate)"}
+        json.dump(traffic, open(tpath, "w"), indent=1)
+    for k, v in out.items():
+        print(k, {c: round(x) for c, x in v.items() if c.startswith("duration")})
+
+
+if __name__ == "__main__":
+    main()
