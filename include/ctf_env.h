@@ -171,6 +171,15 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
 #define CTF_REVERSE_DEFAULT 0xFFFFFFFFu
 int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t reverse_mask, void* stream);
 
+/* The same observation in compact form: the tile planes 1..C-1 of standardise_state are one-hot per cell
+ * (plane k+1 = (relabelled grid == TILES_USED[k]), gridworld_ctf.py:990-1001) and plane 0 holds the single
+ * own-position bit, so
+ *   codes_dev    uint8 [E][N][G][G] or NULL: low 7 bits = index of the plane that is 1 at this cell (0 = none of
+ *                1..C-1), bit 7 = plane 0;  obs[e][i][k][r][c] == (k ? (codes & 127) == k : codes >> 7)
+ *   meta_dev     as ctf_observe
+ * 1/C of the bytes of ctf_observe; what a GPU policy (include/ctf_policy.h) and a rollout buffer consume. */
+int ctf_observe_codes(ctf_env* env, uint8_t* codes_dev, uint16_t* meta_dev, uint32_t reverse_mask, void* stream);
+
 /* ctf_step immediately followed by ctf_observe in ONE launch (the rollout inner loop, ppo.py:59-98). */
 int ctf_step_observe(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev,
                      double* rewards_f64_dev, uint8_t* done_dev, uint8_t* obs_dev, uint16_t* meta_dev,

@@ -1,0 +1,52 @@
+/* ctf_policy.h — C ABI of the policy network's convolutional front on MI355X (same shared library as ctf_env.h).
+ *
+ * Replaces, for inference over whole batches of agents, the first half of the reference's
+ *   Agent.forward(x, x2)                      agent_network.py:30-36
+ *     x = tanh(conv1(x)); x = tanh(conv2(x))  conv1 = Conv2d(C, 16, 3), conv2 = Conv2d(16, 32, 3)   (:13-14)
+ *     x = x.view(-1, 32 * (G-4)^2); x = concat((x, x2), dim=1)
+ * and hands the result to fc1 as a bf16 matrix.  fc1 / fc2 / the heads are plain GEMMs and stay with the BLAS library
+ * (host side: marl-ctf-development_amd/policy_native.py).
+ *
+ * Input is the env's compact observation (ctf_observe_codes, include/ctf_env.h): one byte per (agent, cell) instead of C
+ * one-hot bytes.  All pointers except agent_sel are device pointers owned by the caller; the call only enqueues on
+ * `stream`.  Returns 0, or -1 with ctf_policy_last_error().
+ */
+#ifndef CTF_POLICY_H
+#define CTF_POLICY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Row length (in bf16 elements) of the activation matrix: 32 * (G-4)^2 + meta_len rounded up to a multiple of 32. */
+int32_t ctf_policy_act_stride(int32_t grid_size, int32_t meta_len);
+
+/* act[k * n_envs + e][:] = features of agent agent_sel[k] of env e  (agent-major rows, the order
+ * PPOTrainer.get_single_rollout interleaves agents within a step, ppo.py:74-84).
+ *
+ *   codes_dev        uint8  [n_envs][n_agents][G][G]      from ctf_observe_codes
+ *   meta_dev         binary16 bits [n_envs][n_agents][meta_len]
+ *   agent_sel        HOST int32 [n_sel]: which agents this network plays (e.g. one team), n_sel <= 16
+ *   conv1_frag_dev   bf16 [5][64][8]: conv1.weight * 2 log2(e) in MFMA 16x16x32 A-operand order:
+ *                    [s][lane][j] = W1[out = lane & 15][in = 8 * ((lane >> 4) & 1) + j][tap = 2 s + (lane >> 5)], 0 where
+ *                    in >= C or tap == 9  (tap = 3 * ky + kx)
+ *   conv1_bias_dev   float [16]: conv1.bias * 2 log2(e)
+ *   conv2_frag_dev   bf16 [9][64][8]: [tap][lane][j] = W2[out = lane & 31][in = 8 * (lane >> 5) + j][tap] * 2 log2(e)
+ *   conv2_bias_dev   float [32]: conv2.bias * 2 log2(e)
+ *   act_dev          bf16 [n_sel * n_envs][ctf_policy_act_stride()], 16-byte aligned.  Column of conv2 output channel c
+ *                    at position p (row-major over (G-4)^2): ((c / 4) * P2 + p) * 4 + c % 4, P2 = (G-4)^2; then the
+ *                    meta_len metadata values; then zeros.  (fc1.weight's columns are permuted to this order once.)
+ */
+int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* meta_dev, int32_t n_envs, int32_t n_agents,
+                        int32_t grid_size, int32_t meta_len, const int32_t* agent_sel, int32_t n_sel,
+                        const void* conv1_frag_dev, const float* conv1_bias_dev, const void* conv2_frag_dev,
+                        const float* conv2_bias_dev, uint16_t* act_dev, int32_t device_id, void* stream);
+
+const char* ctf_policy_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -13,15 +13,15 @@ or, for drop-in use with the reference's own scripts, put this directory first o
 ``from gridworld_ctf import GridworldCtf`` resolves here.
 """
 from . import _abi, config, configs, sharding  # noqa: F401
-from .gridworld_ctf import GridworldCtf, VecGridworldCtf  # noqa: F401
+from .gridworld_ctf import GridworldCtf, VecGridworldCtf, expand_codes  # noqa: F401
 from .maps import CtfScenarios  # noqa: F401
 from .rollout import BatchedRolloutCollector  # noqa: F401
 from .duel import batched_duel  # noqa: F401
 
 
 def __getattr__(name):  # the policy module needs torch.nn: import it only when asked for
-    if name == "policy":
+    if name in ("policy", "policy_native"):
         import importlib
 
-        return importlib.import_module(__name__ + ".policy")
+        return importlib.import_module(__name__ + "." + name)
     raise AttributeError(name)

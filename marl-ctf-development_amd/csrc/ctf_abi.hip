@@ -18,6 +18,7 @@ extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint6
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
 extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
+extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
 
@@ -124,6 +125,7 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     d->CGG = C * G * G; d->obs_bytes = N * d->CGG;
     if (!make_fastdiv((uint32_t)d->CGG, (uint32_t)d->obs_bytes + 16, &d->div_cgg) ||
         !make_fastdiv((uint32_t)d->GG, (uint32_t)d->CGG + 16, &d->div_gg) ||
+        !make_fastdiv((uint32_t)d->GG, (uint32_t)(N * d->GG) + 16, &d->div_gg_row) ||
         !make_fastdiv((uint32_t)G, (uint32_t)d->GS + 4, &d->div_g) ||
         !make_fastdiv((uint32_t)d->M, (uint32_t)(N * d->M) + 64, &d->div_m) ||
         !make_fastdiv((uint32_t)N, (uint32_t)(64 * N) + 64, &d->div_n) ||
@@ -354,6 +356,16 @@ extern "C" int ctf_observe(ctf_env* h, uint8_t* obs, uint16_t* meta, uint32_t re
     if (!obs && !meta) return CTF_OK;
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+extern "C" int ctf_observe_codes(ctf_env* h, uint8_t* codes, uint16_t* meta, uint32_t reverse_mask, void* stream) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (!codes && !meta) return CTF_OK;
+    DeviceGuard guard(h->device);
+    const uint32_t rev = resolve_reverse(h, reverse_mask);
+    if (codes) HIP_TRY(ctf_launch_observe_codes(h->d, h->p, codes, rev, h->n_cus, (hipStream_t)stream));
+    if (meta) HIP_TRY(ctf_launch_observe(h->d, h->p, nullptr, meta, rev, h->n_cus, (hipStream_t)stream));
     return CTF_OK;
 }
 

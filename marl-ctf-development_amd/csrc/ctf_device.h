@@ -37,6 +37,7 @@ struct DevCfg {
     int32_t off_pos, off_flag, off_perm, off_inv, off_misc;  // record offsets (hp is at 0)
     int32_t default_reverse;        // bit i = (team(i) == 1)
     FastDiv div_cgg, div_gg, div_g, div_m, div_n, div_gq, div_rq, div_mn, div_mw;
+    FastDiv div_gg_row;             // / GG over 0 .. N*GG (the compact observation's rows)
     int32_t step_lanes_override;    // 0 = automatic; set from CTF_STEP_W for profiling
     double heal, tag_p, guard_mult, vault_cost, vault_min;
     double r_capture, r_step, r_tag, win_scalar, loss_scalar, punish;

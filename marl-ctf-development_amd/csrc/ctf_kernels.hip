@@ -1078,6 +1078,80 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// compact observation: one byte per (agent, cell)
+// ------------------------------------------------------------------------------------------------
+// standardise_state's planes 1..C-1 are one-hot per cell (plane k+1 = (relabelled grid == TILES_USED[k]),
+// gridworld_ctf.py:990-1001) and plane 0 has the single own-position bit, so a whole [C][G][G] block is carried by
+// G*G bytes: codes[e][i][d] = index of the tile plane that is 1 at cell d of agent i's view (0 = none), bit 7 = plane 0.
+// A policy that consumes the codes directly (ctf_policy.hip) never needs the 14x larger one-hot block.
+// Per env a wave builds the (viewer team, reversed?) code maps that are in use (at most 4) in LDS; every agent's row is
+// its map plus the own-position bit.  Per-wave LDS: [grid GS][rec RS][self cell u16[16]][maps 4 x GGp], GGp = GG rounded to 4.
+__host__ __device__ inline int codes_wave_bytes(int GS, int RS, int GG) { return GS + RS + 32 + 4 * ((GG + 3) & ~3); }
+
+template <bool DWORDS>
+__global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ codes, uint32_t reverse_mask) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int wpb = blockDim.x / WAVE;
+    const int N = cfg.N, G = cfg.G, GG = cfg.GG, GGp = (GG + 3) & ~3;
+    uint8_t* wl = (uint8_t*)lds + wave * codes_wave_bytes(cfg.GS, cfg.RS, GG);
+    uint8_t* sgrid = wl;
+    uint8_t* srec = wl + cfg.GS;
+    uint16_t* selfc = (uint16_t*)(srec + cfg.RS);
+    uint8_t* maps = (uint8_t*)(selfc + 16);
+    const ObsSlots slots = obs_slots(cfg, reverse_mask);
+    uint32_t slot_pack = 0;  // 2 bits per agent
+    for (int i = 0; i < N; i++) slot_pack |= (uint32_t)(cfg.team[i] * 2 + (int)((reverse_mask >> i) & 1u)) << (2 * i);
+    const int row = N * GG;
+    for (int e = blockIdx.x * wpb + wave; e < cfg.n_envs; e += gridDim.x * wpb) {
+        for (int w = lane; w < cfg.GS / 4; w += WAVE) ((uint32_t*)sgrid)[w] = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];
+        if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = ((const uint32_t*)(p.rec + (size_t)e * cfg.RS))[lane];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < N) {
+            const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
+            const int r = ps[2 * lane], c = ps[2 * lane + 1];
+            selfc[lane] = (uint16_t)(((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c);
+        }
+#pragma unroll
+        for (int slot = 0; slot < 4; slot++) {
+            if (!slots.a[slot]) continue;  // uniform
+            const uint64_t lut = pin64(cfg.chan_lut[slot >> 1]);
+            for (int d = lane; d < GG; d += WAVE) {
+                const int r = (int)fdiv((uint32_t)d, cfg.div_g), c = d - r * G;
+                const int src = (slot & 1) ? flip_cell(cfg, d, r, c) : d;  // every flip is an involution
+                const uint32_t v = sgrid[src];
+                uint32_t code = (((v & 8u) ? (uint32_t)(lut >> 32) : (uint32_t)lut) >> (4 * (v & 7u))) & 15u;
+                if (v == 0 || code == CTF_TILE_NONE) code = 0;
+                maps[slot * GGp + d] = (uint8_t)code;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+        __builtin_amdgcn_wave_barrier();
+        uint8_t* out = codes + (size_t)e * row;
+        for (int q = lane; q < (row + 3) / 4; q += WAVE) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int f = 4 * q + b;
+                if (f < row) {
+                    const int i = (int)fdiv((uint32_t)f, cfg.div_gg_row), d = f - i * GG;
+                    const uint32_t sl = (slot_pack >> (2 * i)) & 3u;
+                    uint32_t v = maps[sl * GGp + d];
+                    if (d == (int)selfc[i]) v |= 0x80u;
+                    if (DWORDS) word |= v << (8 * b);
+                    else out[f] = (uint8_t)v;
+                }
+            }
+            if (DWORDS) ((uint32_t*)out)[q] = word;
+        }
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bulk export of the evaluation counters
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void k_export_counters(DevCfg cfg, DevPtrs p, int32_t* metrics, int32_t* captures, int32_t* steps) {
@@ -1181,6 +1255,17 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     if (align == 16) hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     else if (align == 4) hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
+    return hipGetLastError();
+}
+extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint32_t reverse_mask, int n_cus,
+                                               hipStream_t st) {
+    const int wpb = 4;
+    const size_t sh = (size_t)wpb * codes_wave_bytes(cfg.GS, cfg.RS, cfg.GG);
+    int blocks = (cfg.n_envs + wpb - 1) / wpb;
+    if (blocks > n_cus * 8) blocks = n_cus * 8;
+    const bool dwords = ((cfg.N * cfg.GG) % 4) == 0 && ((uintptr_t)codes % 4) == 0;
+    if (dwords) hipLaunchKernelGGL(k_observe_codes<true>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, reverse_mask);
+    else hipLaunchKernelGGL(k_observe_codes<false>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, reverse_mask);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg& cfg, const DevPtrs& p, int32_t* metrics, int32_t* captures, int32_t* steps,

@@ -42,6 +42,19 @@ def _as_seed_array(seeds, n):
     return arr
 
 
+def expand_codes(codes, n_channels):
+    """codes uint8 [..., G, G] (observe_codes) -> the one-hot planes uint8 [..., C, G, G] of standardise_state
+    (torch tensor or numpy array)."""
+    if isinstance(codes, np.ndarray):
+        k = np.arange(n_channels, dtype=np.uint8).reshape((n_channels, 1, 1))
+        low, c = (codes & 0x7F)[..., None, :, :], codes[..., None, :, :]
+        return np.where(k == 0, c >> 7, (low == k) & (k > 0)).astype(np.uint8)
+    torch = _torch()
+    k = torch.arange(n_channels, dtype=torch.uint8, device=codes.device).reshape((n_channels, 1, 1))
+    low, c = (codes & 0x7F).unsqueeze(-3), codes.unsqueeze(-3)
+    return torch.where(k == 0, c >> 7, ((low == k) & (k > 0)).to(torch.uint8))
+
+
 class VecGridworldCtf:
     """``n_envs`` GridworldCtf instances on one MI355X.
 
@@ -79,14 +92,35 @@ class VecGridworldCtf:
         self.rewards = torch.zeros((E, N), dtype=torch.float32, device=self.device)
         self.rewards64 = torch.zeros((E, N), dtype=torch.float64, device=self.device)
         self.done = torch.zeros((E,), dtype=torch.uint8, device=self.device)
-        self.obs = torch.zeros((E, N, self.N_CHANNELS, self.GRID_SIZE, self.GRID_SIZE), dtype=torch.uint8, device=self.device)
+        self._obs = None  # uint8 [E, N, C, G, G]: allocated (and placed) on first use — a codes-only caller never pays for it
+        self._codes = None
         self.meta = torch.zeros((E, N, self.META_LEN), dtype=torch.float16, device=self.device)
         self.seed(py_seeds, np_seeds)
         if tune_placement is None:
-            tune_placement = self.obs.numel() > (256 << 20)
+            tune_placement = E * N * self.N_CHANNELS * self.GRID_SIZE ** 2 > (256 << 20)
+        self._tune_placement = bool(tune_placement)
         self.placement_probe_ms = None
-        if tune_placement:
-            self._tune_obs_placement()
+
+    @property
+    def obs(self):
+        if self._obs is None:
+            torch = _torch()
+            self._obs = torch.zeros((self.n_envs, self.N_AGENTS, self.N_CHANNELS, self.GRID_SIZE, self.GRID_SIZE),
+                                    dtype=torch.uint8, device=self.device)
+            if self._tune_placement:
+                self._tune_obs_placement()
+        return self._obs
+
+    @obs.setter
+    def obs(self, buf):
+        self._obs = buf
+
+    @property
+    def codes(self):
+        if self._codes is None:
+            self._codes = _torch().zeros((self.n_envs, self.N_AGENTS, self.GRID_SIZE, self.GRID_SIZE), dtype=_torch().uint8,
+                                         device=self.device)
+        return self._codes
 
     def _tune_obs_placement(self, tries=10, good_enough=0.92):
         """Keep the candidate allocation the render streams into fastest (see __init__); frees the others."""
@@ -183,6 +217,14 @@ class VecGridworldCtf:
         _abi.check(self._lib.ctf_observe(self._h, C.c_void_p(self.obs.data_ptr()) if obs else None,
                                          C.c_void_p(self.meta.data_ptr()) if meta else None, rm, self._stream()), self._lib)
         return self.obs, self.meta
+
+    def observe_codes(self, reverse_mask=None, codes=True, meta=True):
+        """The observation in compact form -> (codes uint8 [E, N, G, G], meta float16 [E, N, 2N+6]): low 7 bits = the tile
+        plane (1..C-1) that is 1 at the cell, 0 = none; bit 7 = plane 0 (own position).  ``expand_codes`` gives the planes."""
+        rm = _abi.REVERSE_DEFAULT if reverse_mask is None else int(reverse_mask) & ((1 << self.N_AGENTS) - 1)
+        _abi.check(self._lib.ctf_observe_codes(self._h, C.c_void_p(self.codes.data_ptr()) if codes else None,
+                                               C.c_void_p(self.meta.data_ptr()) if meta else None, rm, self._stream()), self._lib)
+        return self.codes, self.meta
 
     def step_observe(self, actions, auto_reset=False, want_f64=False, reverse_mask=None):
         """step() then observe() in one call -> (rewards, done, obs, meta)."""

@@ -1,5 +1,5 @@
 """CPU-side checks of the boundary: the HIP library loads without a GPU, exports every symbol that
-include/ctf_env.h declares, and the ctypes mirror matches the compiled struct layouts.  No compute calls."""
+include/*.h declare, and the ctypes mirror matches the compiled struct layouts.  No compute calls."""
 import ctypes
 import importlib
 import os
@@ -12,9 +12,12 @@ abi = importlib.import_module("marl-ctf-development_amd._abi")
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ctf_env.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ctf_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in ("ctf_env.h", "ctf_policy.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(ctf_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 @pytest.fixture(scope="module")

@@ -62,6 +62,10 @@ def test_golden_trajectory(name):
         assert int(done[0]) == int(z["done"][t]), ctx
         assert np.array_equal(obs[0].cpu().numpy(), case.unpack_obs(z["obs"][t])), ctx
         assert np.array_equal(meta[0].cpu().numpy().view(np.uint16), z["meta"][t]), ctx
+        if t % 4 == 0 or t in extra:  # the compact form carries the same planes
+            codes, meta_c = vec.observe_codes()
+            assert np.array_equal(pkg.expand_codes(codes[0].cpu().numpy(), case.obs_shape[1]), case.unpack_obs(z["obs"][t])), ctx
+            assert np.array_equal(meta_c[0].cpu().numpy().view(np.uint16), z["meta"][t]), ctx
         if t % 9 == 0 or t in extra or t >= case.T - 3:
             s = view_arrays(vec.get_state(0), n, g)
             assert np.array_equal(s["grid"], z["grid"][t]), ctx
@@ -77,6 +81,10 @@ def test_golden_trajectory(name):
             assert np.array_equal(o_unrev, case.unpack_obs(z["extra_obs_unrev"][extra[t]])), ctx
             o_rev = vec.observe(reverse_mask=(1 << n) - 1)[0][0].cpu().numpy()
             assert np.array_equal(o_rev, case.unpack_obs(z["extra_obs_rev"][extra[t]])), ctx
+            c_unrev = vec.observe_codes(reverse_mask=0, meta=False)[0][0].cpu().numpy()
+            assert np.array_equal(pkg.expand_codes(c_unrev, case.obs_shape[1]), o_unrev), ctx
+            c_rev = vec.observe_codes(reverse_mask=(1 << n) - 1, meta=False)[0][0].cpu().numpy()
+            assert np.array_equal(pkg.expand_codes(c_rev, case.obs_shape[1]), o_rev), ctx
 
     s = view_arrays(vec.get_state(0), n, g)
     assert np.array_equal(s["metrics"], z["metrics"])
@@ -113,6 +121,9 @@ def test_batch_matches_oracle(name, n_envs, steps, log_metrics):
     for t in range(steps):
         vec.random_actions(acts, seed=0xC0FFEE, step=t, env_offset=11)
         rewards, done, obs, meta = vec.step_observe(acts, auto_reset=auto_reset, want_f64=True)
+        if t % 8 == 0:  # compact observation == the one-hot block, every env (dword and byte store paths)
+            codes, _ = vec.observe_codes(meta=False)
+            assert torch.equal(pkg.expand_codes(codes, vec.N_CHANNELS), obs), f"{name} step {t}: codes"
         a = acts.cpu().numpy()
         r64 = vec.rewards64.cpu().numpy()
         d = done.cpu().numpy()

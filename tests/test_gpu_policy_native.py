@@ -1,0 +1,131 @@
+"""The native policy front (ctf_policy_features: conv1 -> tanh -> conv2 -> tanh -> flatten ++ metadata, bf16 MFMA) and the
+inference path built on it, against
+  * a float64 emulation of exactly what the kernel computes (bf16-rounded scaled weights, bf16-rounded hidden
+    activations): agreement to one bf16 ulp — this pins every index of the kernel;
+  * the float32 network (the torch reference of this floating-point kernel): tolerance 3e-2 on activations in [-1, 1];
+  * the reference's own Agent outputs on reference observations (tests/golden/policy_arena.npz): logits within 0.15,
+    values within 0.25 (bf16 operands through four layers; the float32 path of policy.py holds 1e-4).
+"""
+import importlib
+import math
+import os
+
+import numpy as np
+import pytest
+
+from _cases import GOLDEN, pkg
+from _policy_weights import fill_
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+native = importlib.import_module("marl-ctf-development_amd.policy_native")
+S = 2.0 / math.log(2.0)
+
+
+def encode(planes):
+    """one-hot planes [..., C, G, G] -> codes [..., G, G] (the inverse of expand_codes)."""
+    c = planes.shape[-3]
+    k = np.arange(1, c, dtype=np.uint8).reshape((c - 1, 1, 1))
+    return ((planes[..., 1:, :, :] * k).sum(axis=-3) | (planes[..., 0, :, :] << 7)).astype(np.uint8)
+
+
+def bf16(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def emulate(net, planes, meta):
+    """float64 evaluation of the kernel's arithmetic: planes [B, C, G, G] (0/1), meta float16 [B, M] -> [B, 32*P2 + M]."""
+    F = torch.nn.functional
+    t = lambda z: 1.0 - 2.0 / (torch.exp2(z) + 1.0)
+    w1, b1 = bf16(net.conv1.weight.detach().cpu().double() * S), (net.conv1.bias.detach().cpu().double() * S).float().double()
+    w2, b2 = bf16(net.conv2.weight.detach().cpu().double() * S), (net.conv2.bias.detach().cpu().double() * S).float().double()
+    h1 = bf16(t(F.conv2d(planes.double(), w1, b1)))
+    h2 = bf16(t(F.conv2d(h1, w2, b2)))
+    return torch.cat((h2.flatten(1), bf16(meta.float())), dim=1)
+
+
+def unpermute(net, feats):
+    """kernel column order -> the reference's flatten order; also checks the padding columns are zero."""
+    order = native.act_column_order(net.grid_size, net.metadata_size)
+    f = feats.float().cpu()
+    assert bool((f[:, order < 0] == 0).all())
+    out = torch.zeros((f.shape[0], int(order.max()) + 1), dtype=torch.float64)
+    out[:, order[order >= 0]] = f[:, order >= 0].double()
+    return out
+
+
+def _golden():
+    z = np.load(os.path.join(GOLDEN, "policy_arena.npz"))
+    shape = tuple(int(x) for x in z["grid_shape"])
+    grids = np.unpackbits(z["grids"])[: int(np.prod(shape))].reshape(shape)  # [T*N, C, G, G], step-major
+    metas = z["metas"].view(np.float16)
+    n = 8
+    return z, grids, metas, n
+
+
+def test_features_match_the_emulation_and_the_float32_network_on_reference_observations():
+    z, grids, metas, n = _golden()
+    T = grids.shape[0] // n
+    c, g = grids.shape[1], grids.shape[2]
+    net = fill_(native.CtfPolicyNative(9, c, g, metas.shape[1])).cuda()
+    codes = torch.tensor(encode(grids).reshape(T, n, g, g), device="cuda")
+    meta = torch.tensor(metas.reshape(T, n, -1), device="cuda")
+    feats = net.features_from_codes(codes, meta, list(range(n)))       # row k * T + e
+    got = unpermute(net, feats).reshape(n, T, -1).transpose(0, 1).reshape(T * n, -1)  # -> row e * n + k
+    want = emulate(net, torch.tensor(grids), torch.tensor(metas))
+    ulp = 2.0 ** -7
+    diff = (got - want).abs()
+    assert float(diff.max()) <= ulp, float(diff.max())
+    assert float((diff > 0).double().mean()) < 0.02  # a rounding flip here and there (accumulation order), nothing more
+    with torch.no_grad():
+        cpu = fill_(native.CtfPolicy(9, c, g, metas.shape[1]))
+        x = torch.tanh(cpu.conv2(torch.tanh(cpu.conv1(torch.tensor(grids, dtype=torch.float32)))))
+        ref32 = torch.cat((x.flatten(1), torch.tensor(metas).float()), dim=1).double()
+    assert float((got - ref32).abs().max()) < 3e-2  # bf16 operands vs the float32 network, activations in [-1, 1]
+    # a subset of agents, in another order: the same rows
+    sub = net.features_from_codes(codes, meta, [5, 1])
+    assert torch.equal(sub[:T], feats[5 * T:6 * T]) and torch.equal(sub[T:], feats[T:2 * T])
+
+
+@pytest.mark.parametrize("g,c,n,e", [(11, 8, 4, 70), (15, 14, 8, 33), (20, 14, 8, 9), (7, 5, 2, 130), (32, 15, 3, 5)])
+def test_features_on_random_codes_for_other_grid_sizes(g, c, n, e):
+    """Every kernel instantiation (G = 11, 15 and the generic one) on random codes — partial waves, odd sizes."""
+    rng = np.random.default_rng(g * 100 + c)
+    m = 2 * n + 6
+    low = rng.integers(0, c, (e, n, g, g)).astype(np.uint8) * (rng.random((e, n, g, g)) < 0.3)
+    selfbit = (rng.random((e, n, g, g)) < 0.02).astype(np.uint8) << 7
+    codes = (low | selfbit).astype(np.uint8)
+    metas = rng.random((e, n, m)).astype(np.float16)
+    net = fill_(native.CtfPolicyNative(9, c, g, m)).cuda()
+    feats = net.features_from_codes(torch.tensor(codes, device="cuda"), torch.tensor(metas, device="cuda"), list(range(n)))
+    got = unpermute(net, feats).reshape(n, e, -1).transpose(0, 1).reshape(e * n, -1)
+    planes = torch.tensor(pkg.expand_codes(codes, c).reshape(e * n, c, g, g))
+    want = emulate(net, planes, torch.tensor(metas.reshape(e * n, m)))
+    assert float((got - want).abs().max()) <= 2.0 ** -7
+
+
+def test_native_inference_is_close_to_the_reference_agent_and_respects_the_mask():
+    z, grids, metas, n = _golden()
+    T = grids.shape[0] // n
+    c, g = grids.shape[1], grids.shape[2]
+    net = fill_(native.CtfPolicyNative(9, c, g, metas.shape[1])).cuda()
+    codes = torch.tensor(encode(grids).reshape(T, n, g, g), device="cuda")
+    meta = torch.tensor(metas.reshape(T, n, -1), device="cuda")
+    with torch.no_grad():
+        value, logits = net.trunk_from_codes(codes, meta, list(range(n)))
+        back = lambda t: t.reshape(n, T, -1).transpose(0, 1).reshape(T * n, -1).cpu().numpy()
+        assert np.abs(back(logits) - z["logits"]).max() < 0.15
+        assert np.abs(back(value) - z["value"]).max() < 0.25
+        masks = torch.tensor(z["masks"].reshape(T, n).T.reshape(-1).copy(), device="cuda")  # agent-major like the rows
+        action, logprob, entropy, _ = net.act_from_codes(codes, meta, list(range(n)), masks)
+        assert bool((action[masks == 1] < 5).all())  # decision 1: only actions 0..4 (agent_network.py:66-75)
+        assert bool(torch.isfinite(logprob).all()) and bool(torch.isfinite(entropy).all())
+        # the stock forward of the same module (one-hot planes in, bf16 autocast) agrees with the native path
+        v2, l2 = net(torch.tensor(grids, device="cuda"), torch.tensor(metas, device="cuda"))
+        assert np.abs(back(logits) - l2.cpu().numpy()).max() < 0.15
+
+
+def test_native_path_fails_loudly_off_gpu():
+    net = native.CtfPolicyNative(9, 14, 15, 22)
+    with pytest.raises(pkg._abi.CtfLibraryError):
+        net.prepare()
