@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Stage timings of the native policy path on the arena shape: observe_codes, ctf_policy_features, fc1, fc2, heads, sampling.
+
+    python tools/policy_native_bench.py [envs]        (8 agents per env => B = 8 * envs samples)
+"""
+import importlib
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def timed(fn, reps=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    E = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    pkg = importlib.import_module("marl-ctf-development_amd")
+    native = pkg.policy_native
+    kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+    vec = pkg.VecGridworldCtf(E, device=0, **kw)
+    acts = torch.zeros((E, vec.N_AGENTS), dtype=torch.int8, device="cuda")
+    for t in range(20):
+        vec.random_actions(acts, 7, t)
+        vec.step(acts)
+    net = native.CtfPolicyNative(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN).cuda().prepare()
+    p = net._prep
+    sel = list(range(vec.N_AGENTS))
+    B = E * len(sel)
+    out = {"envs": E, "B": B}
+    with torch.no_grad():
+        out["observe_codes"] = timed(lambda: vec.observe_codes())
+        out["observe_codes_only"] = timed(lambda: vec.observe_codes(meta=False))
+        codes, meta = vec.observe_codes()
+        feats = torch.zeros((B, p["kp"]), dtype=torch.bfloat16, device="cuda")
+        out["features"] = timed(lambda: net.features_from_codes(codes, meta, sel, out=feats))
+        F = torch.nn.functional
+        out["fc1"] = timed(lambda: F.linear(feats, p["fc1_w"], p["fc1_b"]))
+        x1 = torch.tanh_(F.linear(feats, p["fc1_w"], p["fc1_b"]))
+        out["fc1_tanh"] = timed(lambda: torch.tanh_(x1))
+        out["fc2"] = timed(lambda: F.linear(x1, p["fc2_w"], p["fc2_b"]))
+        x2 = torch.tanh_(F.linear(x1, p["fc2_w"], p["fc2_b"]))
+        out["heads_fp32"] = timed(lambda: torch.addmm(p["head_b"], x2.float(), p["head_w"]))
+        out["trunk_from_codes"] = timed(lambda: net.trunk_from_codes(codes, meta, sel))
+        mask = torch.ones(B, device="cuda")
+        out["act_from_codes"] = timed(lambda: net.act_from_codes(codes, meta, sel, mask))
+    out = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}
+    out["samples_per_s_act"] = round(B / (out["act_from_codes"] * 1e-3))
+    flop = 2 * (169 * 16 * 14 * 9 + 121 * 32 * 16 * 9)
+    out["features_tflops_conv"] = round(B * flop / (out["features"] * 1e-3) / 1e12, 1)
+    out["features_act_write_gbs"] = round(B * p["kp"] * 2 / (out["features"] * 1e-3) / 1e9, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

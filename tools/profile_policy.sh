@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 passes over the native policy path (run on the GPU box through gpurun): bash tools/profile_policy.sh <tag> [envs]
+set -o pipefail
+TAG=${1:-r01}
+ENVS=${2:-65536}
+OUT=$PWD/gpurun_out/prof_policy_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="$PWD/tools/policy_native_bench.py $ENVS"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $CMD > $OUT/trace.log 2>&1 || echo "trace failed"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $CMD > $OUT/pmc_sq.log 2>&1 || echo "pmc sq failed"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 $CMD > $OUT/pmc_sq2.log 2>&1 || echo "pmc sq2 failed"
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS SQ_WAVE32_INSTS --kernel-trace --output-format csv -d $OUT/pmc_sq3 -- python3 $CMD > $OUT/pmc_sq3.log 2>&1 || echo "pmc sq3 failed"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $CMD > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $CMD > $OUT/pmc_write.log 2>&1 || echo "pmc write failed"
+find $OUT -name "*.csv" | wc -l

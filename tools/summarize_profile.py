@@ -60,7 +60,7 @@ def main():
         with open(os.path.join(root, tag + "_kernel_stats.csv"), "w", newline="") as f:
             csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows([head] + body)
     out = {}
-    for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
         path = one(os.path.join(src, p, "**", "*_counter_collection.csv"))
         if path:
             pmc_pass(path, p, out)
