@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--envs", type=int, default=16384)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--policy", choices=["native", "torch"], default="native",
+                    help="native: compact observation + MFMA conv front (policy_native.py); torch: one-hot planes + stock PyTorch modules")
     args = ap.parse_args()
     import torch
 
@@ -27,7 +29,10 @@ def main():
     kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
     vec = pkg.VecGridworldCtf(args.envs, device=0, **kw)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    nets = [pkg.policy.CtfPolicy(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN, compute_dtype=dt).cuda() for _ in range(2)]
+    if args.policy == "native":
+        nets = [pkg.policy_native.CtfPolicyNative(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN).cuda().prepare() for _ in range(2)]
+    else:
+        nets = [pkg.policy.CtfPolicy(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN, compute_dtype=dt).cuda() for _ in range(2)]
     col = pkg.BatchedRolloutCollector(vec, args.steps, 0)
     col.collect(*nets)  # warm-up (MIOpen kernel selection)
     torch.cuda.synchronize()
@@ -40,13 +45,14 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        vec.observe()
+        vec.observe_codes() if args.policy == "native" else vec.observe()
         vec.step(acts)
     torch.cuda.synchronize()
     env_s = time.perf_counter() - t1
     print(json.dumps({
         "metric": "end-to-end rollout env-steps/sec (env + 2 policy networks, self-play)", "value": args.envs * args.steps / dt_s,
-        "unit": "env-steps/s", "n_gpus": 1, "envs": args.envs, "steps": args.steps, "policy_dtype": args.dtype,
+        "unit": "env-steps/s", "n_gpus": 1, "envs": args.envs, "steps": args.steps, "policy": args.policy,
+        "policy_dtype": "bf16" if args.policy == "native" else args.dtype,
         "policy_samples_per_sec": args.envs * args.steps * vec.N_AGENTS / dt_s, "env_share_of_time": env_s / dt_s,
     }))
 

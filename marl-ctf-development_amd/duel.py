@@ -19,20 +19,13 @@ def batched_duel(vec, agent, opponent, max_steps=256):
     import torch
 
     col = BatchedRolloutCollector(vec, 1, 0)  # reuses the policy plumbing; its rollout buffers hold one step
+    use_codes = col.use_codes(agent, opponent)  # policies with a compact-observation path (policy_native.py) get the code bytes
     game_steps = int(vec.cfg.game_steps)
     n_steps = min(game_steps, int(max_steps) + 1)
     vec.reset()
     with torch.no_grad():
         for _ in range(n_steps):
-            obs, meta = vec.observe()
-            a0 = col._policy(agent, obs, meta, col.trained_idx)[0]
-            a1 = col._policy(opponent, obs, meta, col.others_idx)[0]
-            env_act = col._env_actions
-            env_act[:, col.trained_idx] = a0.to(torch.int8).transpose(0, 1)
-            env_act[:, col.others_idx] = a1.to(torch.int8).transpose(0, 1)
-            mapped = col.rev_lut[env_act.long()]
-            env_act = torch.where(col.is_team1[None, :], mapped, env_act).contiguous()
-            vec.step(env_act)
+            vec.step(col.joint_actions(agent, opponent, use_codes)[1])
     metrics, caps, _ = vec.counters()
     result = torch.sign(caps[:, 0] - caps[:, 1]).to(torch.int8)
     return dict(result=result, team_flag_captures=caps, metrics=metrics, steps=n_steps)
@@ -46,6 +39,7 @@ def duel_trajectory(vec, agent, opponent, env_index=0, max_steps=256):
     import torch
 
     col = BatchedRolloutCollector(vec, 1, 0)
+    use_codes = col.use_codes(agent, opponent)
     n, g = vec.N_AGENTS, vec.GRID_SIZE
     scen = vec.derived["kwargs"]["SCENARIO"]
     vec.reset()
@@ -74,14 +68,7 @@ def duel_trajectory(vec, agent, opponent, env_index=0, max_steps=256):
     n_steps = min(int(vec.cfg.game_steps), int(max_steps) + 1)
     with torch.no_grad():
         for _ in range(n_steps):
-            obs, meta = vec.observe()
-            a0 = col._policy(agent, obs, meta, col.trained_idx)[0]
-            a1 = col._policy(opponent, obs, meta, col.others_idx)[0]
-            env_act = col._env_actions
-            env_act[:, col.trained_idx] = a0.to(torch.int8).transpose(0, 1)
-            env_act[:, col.others_idx] = a1.to(torch.int8).transpose(0, 1)
-            env_act = torch.where(col.is_team1[None, :], col.rev_lut[env_act.long()], env_act).contiguous()
-            vec.step(env_act)
+            vec.step(col.joint_actions(agent, opponent, use_codes)[1])
             grid, new_pos, has_flag, caps = snapshot()
             movement.append([{"x": new_pos[i][1] - pos[i][1], "z": new_pos[i][0] - pos[i][0], "has_flag": has_flag[i]} for i in range(n)])
             tiles.append(tiles_of(grid))

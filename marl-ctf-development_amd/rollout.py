@@ -27,15 +27,19 @@ except ImportError:  # pragma: no cover
 
 
 class BatchedRolloutCollector:
-    def __init__(self, vec, num_steps, team_to_train, obs_dtype=None):
+    def __init__(self, vec, num_steps, team_to_train, obs_dtype=None, compact=None):
         """vec: VecGridworldCtf.  num_steps: ENV steps per rollout (the reference's ``args.num_steps``).
-        obs_dtype: dtype of the stored grid states (default uint8, the env's native output; the reference stores float32)."""
+        obs_dtype: dtype of the stored grid states (default uint8, the env's native output; the reference stores float32).
+        compact: feed the policies and fill the rollout buffer with the compact observation (``observe_codes``: one byte
+        per cell instead of C one-hot bytes; the rollout then holds ``grid_codes`` [S, E, G, G] and ``expand_codes`` gives
+        the planes of any minibatch).  None = whenever both policies offer ``act_from_codes`` (policy_native.py)."""
         import torch
 
         self.torch = torch
         self.vec = vec
         self.T = int(num_steps)
         self.team = int(team_to_train)
+        self.compact = compact
         n, dev = vec.N_AGENTS, vec.device
         teams = [vec.AGENT_TEAMS[i] for i in range(n)]
         types = [vec.AGENT_TYPES[i] for i in range(n)]
@@ -53,8 +57,9 @@ class BatchedRolloutCollector:
         self.is_team1 = torch.tensor([t == 1 for t in teams], device=dev)
         self.obs_dtype = obs_dtype or torch.uint8
         E, S = vec.n_envs, self.T * self.A
-        c, g, m = vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN
-        self.grid_states = torch.zeros((S, E, c, g, g), dtype=self.obs_dtype, device=dev)
+        m = vec.META_LEN
+        self.grid_states = None  # [S, E, C, G, G], allocated by the first plane-mode collect
+        self.grid_codes = None   # [S, E, G, G], allocated by the first compact collect
         self.metadata_states = torch.zeros((S, E, m), dtype=torch.float32, device=dev)
         self.actions = torch.zeros((S, E), dtype=torch.float32, device=dev)
         self.use_action_mask = torch.zeros((S, E), dtype=torch.float32, device=dev)
@@ -63,6 +68,11 @@ class BatchedRolloutCollector:
         self.dones = torch.zeros((S, E), dtype=torch.float32, device=dev)
         self.values = torch.zeros((S, E), dtype=torch.float32, device=dev)
         self._env_actions = torch.zeros((E, n), dtype=torch.int8, device=dev)
+
+    def use_codes(self, agent, opponent):
+        if self.compact is None:
+            return hasattr(agent, "act_from_codes") and hasattr(opponent, "act_from_codes")
+        return bool(self.compact)
 
     def _policy(self, net, obs, meta, idx):
         """Run one policy over agents `idx` of every env: batch = E * len(idx), agent-major."""
@@ -76,38 +86,75 @@ class BatchedRolloutCollector:
         return (action.reshape(k, E), logprob.reshape(k, E), value.reshape(k, E), grid.reshape((k, E) + tuple(obs.shape[2:])),
                 md.reshape(k, E, -1), mask.reshape(k, E))
 
+    def _policy_codes(self, net, codes, meta, idx, want_inputs=True):
+        """The same over the compact observation: the network reads the env's code bytes in place."""
+        torch = self.torch
+        E, k = self.vec.n_envs, idx.numel()
+        mask = self.mask_flag.index_select(0, idx)[:, None].expand(-1, E).reshape(-1)
+        action, logprob, _, value = net.act_from_codes(codes, meta, idx.tolist(), mask)
+        grid = md = None
+        if want_inputs:
+            grid = codes.index_select(1, idx).transpose(0, 1)
+            md = meta.index_select(1, idx).transpose(0, 1).to(torch.float32)
+        return action.reshape(k, E), logprob.reshape(k, E), value.reshape(k, E), grid, md, mask.reshape(k, E)
+
+    def joint_actions(self, agent, opponent, use_codes):
+        """One decision of every agent of every env -> (what the trained team's policy returned, env actions int8 [E, N]):
+        team-1 agents' actions are mapped back through the flip (ppo.py:80-83,90-93)."""
+        torch, vec = self.torch, self.vec
+        if use_codes:
+            codes, meta = vec.observe_codes()  # default reversal: team(i) == 1
+            trained = self._policy_codes(agent, codes, meta, self.trained_idx)
+            o_act = self._policy_codes(opponent, codes, meta, self.others_idx, want_inputs=False)[0]
+        else:
+            obs, meta = vec.observe()
+            trained = self._policy(agent, obs, meta, self.trained_idx)
+            o_act = self._policy(opponent, obs, meta, self.others_idx)[0]
+        env_act = self._env_actions
+        env_act[:, self.trained_idx] = trained[0].to(torch.int8).transpose(0, 1)
+        env_act[:, self.others_idx] = o_act.to(torch.int8).transpose(0, 1)
+        mapped = self.rev_lut[env_act.long()]
+        return trained, torch.where(self.is_team1[None, :], mapped, env_act).contiguous()
+
     def collect(self, agent, opponent, reset=True):
-        """-> dict with the tensors ``get_single_rollout`` returns, each with an env axis after the slot axis."""
+        """-> dict with the tensors ``get_single_rollout`` returns, each with an env axis after the slot axis.  In compact
+        mode ``grid_codes`` / ``next_grid_codes`` stand in for ``grid_states`` / ``next_grid_state``."""
         torch, vec, A = self.torch, self.vec, self.A
+        use_codes = self.use_codes(agent, opponent)
+        E, S, g = vec.n_envs, self.T * self.A, vec.GRID_SIZE
+        if use_codes and self.grid_codes is None:
+            self.grid_codes = torch.zeros((S, E, g, g), dtype=torch.uint8, device=vec.device)
+        if not use_codes and self.grid_states is None:
+            self.grid_states = torch.zeros((S, E, vec.N_CHANNELS, g, g), dtype=self.obs_dtype, device=vec.device)
         if reset:
             vec.reset()  # ppo.py:57
         self.dones.zero_()
         done = None
         with torch.no_grad():
             for t in range(self.T):
-                obs, meta = vec.observe()  # default reversal: team(i) == 1
-                a_act, a_lp, a_val, a_grid, a_md, a_mask = self._policy(agent, obs, meta, self.trained_idx)
-                o_act = self._policy(opponent, obs, meta, self.others_idx)[0]
+                (a_act, a_lp, a_val, a_grid, a_md, a_mask), env_act = self.joint_actions(agent, opponent, use_codes)
                 sl = slice(t * A, (t + 1) * A)
-                self.grid_states[sl] = a_grid.to(self.obs_dtype)
+                if use_codes:
+                    self.grid_codes[sl] = a_grid
+                else:
+                    self.grid_states[sl] = a_grid.to(self.obs_dtype)
                 self.metadata_states[sl] = a_md
                 self.values[sl] = a_val
                 self.actions[sl] = a_act.to(torch.float32)
                 self.use_action_mask[sl] = a_mask
                 self.logprobs[sl] = a_lp
-                # actions as the env sees them: team-1 agents' actions are mapped back through the flip
-                env_act = self._env_actions
-                env_act[:, self.trained_idx] = a_act.to(torch.int8).transpose(0, 1)
-                env_act[:, self.others_idx] = o_act.to(torch.int8).transpose(0, 1)
-                mapped = self.rev_lut[env_act.long()]
-                env_act = torch.where(self.is_team1[None, :], mapped, env_act).contiguous()
                 rewards, done = vec.step(env_act)
                 self.rewards[sl] = rewards.index_select(1, self.trained_idx).transpose(0, 1)
-            obs, meta = vec.observe()
             first = self.trained[0]
-            next_grid = obs[:, first].to(torch.float32)
+            if use_codes:
+                codes, meta = vec.observe_codes()
+                next_obs = dict(next_grid_codes=codes[:, first].clone())
+            else:
+                obs, meta = vec.observe()
+                next_obs = dict(next_grid_state=obs[:, first].to(torch.float32))
             next_meta = meta[:, first].to(torch.float32)
             next_done = done.to(torch.float32)
-        return dict(grid_states=self.grid_states, metadata_states=self.metadata_states, actions=self.actions,
-                    use_action_mask=self.use_action_mask, logprobs=self.logprobs, rewards=self.rewards, dones=self.dones,
-                    values=self.values, next_grid_state=next_grid, next_metadata_state=next_meta, next_done=next_done)
+        grids = dict(grid_codes=self.grid_codes) if use_codes else dict(grid_states=self.grid_states)
+        return dict(metadata_states=self.metadata_states, actions=self.actions, use_action_mask=self.use_action_mask,
+                    logprobs=self.logprobs, rewards=self.rewards, dones=self.dones, values=self.values,
+                    next_metadata_state=next_meta, next_done=next_done, **grids, **next_obs)

@@ -34,3 +34,19 @@ class StubDuelPolicy(StubPolicy):
 
     def get_action(self, x, x2, masking_decision_tensor):
         return int(self.get_action_and_value(x, x2, masking_decision_tensor)[0].reshape(-1)[0].item())
+
+
+class StubCodesPolicy(StubDuelPolicy):
+    """The same stub behind the compact-observation interface of policy_native.CtfPolicyNative: it expands the code bytes
+    to the one-hot planes and scores those, so a compact rollout must reproduce the plane rollout bit for bit."""
+
+    def __init__(self, salt, n_channels, expand_codes, n_actions=9):
+        super().__init__(salt, n_actions)
+        self.n_channels, self.expand_codes = int(n_channels), expand_codes
+
+    def act_from_codes(self, codes, meta, agent_idx, masking_decision_tensor, action=None):
+        idx = torch.tensor(list(agent_idx), device=codes.device)
+        g = codes.shape[-1]
+        planes = self.expand_codes(codes.index_select(1, idx).transpose(0, 1).reshape(-1, g, g), self.n_channels)
+        md = meta.index_select(1, idx).transpose(0, 1).reshape(planes.shape[0], -1).to(torch.float32)
+        return self.get_action_and_value(planes, md, masking_decision_tensor)

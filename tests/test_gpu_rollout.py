@@ -8,11 +8,35 @@ import numpy as np
 import pytest
 
 from _cases import GOLDEN, duel_case_names, kwargs_from_json, pkg, rollout_case_names
-from _stub_policy import StubPolicy
+from _stub_policy import StubCodesPolicy, StubPolicy
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 rollout = importlib.import_module("marl-ctf-development_amd.rollout")
+
+
+@pytest.mark.parametrize("name", rollout_case_names())
+def test_compact_rollout_matches_reference_rollout(name):
+    """The same reference rollout through the compact observation (code bytes in, code bytes stored)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(z["case_json"]).decode())
+    kwargs = kwargs_from_json(meta)
+    seed, team, steps = meta["seed"], meta["team"], meta["steps"]
+    seeds = [seed, seed + 1, seed]
+    vec = pkg.VecGridworldCtf(3, device=0, py_seeds=seeds, np_seeds=seeds, **kwargs)
+    col = rollout.BatchedRolloutCollector(vec, steps, team)
+    c = vec.N_CHANNELS
+    out = col.collect(StubCodesPolicy(3 + seed, c, pkg.expand_codes), StubCodesPolicy(5 + seed, c, pkg.expand_codes))
+    assert "grid_states" not in out and vec._obs is None  # the one-hot block was never allocated
+    shape = tuple(meta["grid_shape"])
+    want_grid = np.unpackbits(z["grid_states"])[: int(np.prod(shape))].reshape(shape)
+    for e in (0, 2):
+        assert np.array_equal(pkg.expand_codes(out["grid_codes"][:, e].cpu().numpy(), c), want_grid)
+        for key in ("metadata_states", "actions", "use_action_mask", "logprobs", "values", "rewards", "dones"):
+            assert np.array_equal(out[key][:, e].cpu().numpy(), z[key]), key
+        assert np.array_equal(pkg.expand_codes(out["next_grid_codes"][e].cpu().numpy(), c)[None], z["next_grid_state"].astype(np.uint8))
+        assert np.array_equal(out["next_metadata_state"][e].cpu().numpy()[None], z["next_metadata_state"])
+    vec.close()
 
 
 @pytest.mark.parametrize("name", rollout_case_names())
@@ -62,6 +86,13 @@ def test_batched_duel_matches_reference_duel(name):
         assert int(out["result"][e]) == meta["result"]
         assert out["team_flag_captures"][e].tolist() == meta["captures"]
         assert np.array_equal(out["metrics"][e].cpu().numpy(), z["metrics"])
+    # the same duel through the compact observation
+    c = vec.N_CHANNELS
+    vec_c = pkg.VecGridworldCtf(3, device=0, py_seeds=seeds, np_seeds=seeds, **kwargs)  # fresh: `_arr` survives a re-seed
+    out_c = duel.batched_duel(vec_c, StubCodesPolicy(3 + salt, c, pkg.expand_codes), StubCodesPolicy(5 + salt, c, pkg.expand_codes),
+                              max_steps=meta["max_steps"])
+    assert torch.equal(out_c["metrics"], out["metrics"]) and torch.equal(out_c["result"], out["result"])
+    vec_c.close()
     # the bulk counters agree with the per-env host view
     v = vec.get_state(1)
     assert np.array_equal(out["metrics"][1].cpu().numpy(), np.array([[v.metrics[k][i] for i in range(vec.N_AGENTS)] for k in range(13)]))
