@@ -44,6 +44,30 @@ int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* meta_dev, int3
                         const void* conv1_frag_dev, const float* conv1_bias_dev, const void* conv2_frag_dev,
                         const float* conv2_bias_dev, uint16_t* act_dev, int32_t device_id, void* stream);
 
+/* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
+ *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)
+ *   logits += (mask - 1) * 1e9 with mask = [1]*5 + [0]*(A-5) where the decision is 1, all ones otherwise
+ *   action ~ Categorical(logits) (or the given action); log_prob(action); entropy
+ *
+ *   fc1_out_dev        bf16 [n_samples][256]: fc1's output INCLUDING bias, times 2 log2(e) (scale fc1's weight and bias
+ *                      once; the BLAS GEMM then produces this directly), 16-byte aligned
+ *   fc2_frag_dev       bf16 [4][16][64][8]: [w][s][lane][j] = fc2.weight[32 w + (lane & 31)][16 s + 8 (lane >> 5) + j] * 2 log2(e)
+ *   fc2_bias_dev       float [128]: fc2.bias * 2 log2(e)
+ *   head_frag_dev      bf16 [4][64][8]: [s][lane][j] = H[lane & 15][32 s + 8 (lane >> 4) + j], H rows 0..A-1 =
+ *                      action_head.weight, row A = value_head.weight, other rows 0
+ *   head_bias_dev      float [16] in the same row order
+ *   mask_decision_dev  float [n_samples] (1 => only actions 0..4 legal) or NULL (no masking)
+ *   given_action_dev   int32 [n_samples] to evaluate instead of sampling, or NULL
+ *   seed, offset       Philox4x32-10 key / counter words of the sampler: the uniform of sample i is
+ *                      philox(counter = (i, offset), key = seed).x >> 8 scaled to [0, 1); the action is the inverse CDF
+ *   outputs            action int32, logprob / entropy / value float [n_samples]; logits float [n_samples][A] or NULL
+ */
+int ctf_policy_head(const uint16_t* fc1_out_dev, int64_t n_samples, const void* fc2_frag_dev, const float* fc2_bias_dev,
+                    const void* head_frag_dev, const float* head_bias_dev, const float* mask_decision_dev,
+                    const int32_t* given_action_dev, int32_t n_actions, uint64_t seed, uint64_t offset, int32_t* action_dev,
+                    float* logprob_dev, float* entropy_dev, float* value_dev, float* logits_dev, int32_t device_id,
+                    void* stream);
+
 const char* ctf_policy_last_error(void);
 
 #ifdef __cplusplus

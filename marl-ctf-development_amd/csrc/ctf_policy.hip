@@ -283,6 +283,191 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the network's tail, fused: tanh(fc1 out) -> fc2 -> tanh -> action / value heads -> mask -> sample
+// ------------------------------------------------------------------------------------------------
+// Input is fc1's pre-activation (the BLAS GEMM's bf16 output, bias included, scaled by 2 log2 e like the conv stages).
+// A block of 4 waves takes 128 samples:
+//   a. every wave applies tanh to its 32 rows and parks them as bf16 in LDS xs[128][256] (rows padded by 16 bytes: the
+//      32x32x16 B-operand reads of 32 consecutive samples then fall on 16 distinct 16-byte slots per lane group);
+//   b. fc2 as out[128 ch][128 samples]: wave w owns channels 32 w .. 32 w + 31 (its 16 A fragments stay in registers for
+//      the whole launch) and runs the 4 sample tiles: 64 MFMAs 32x32x16;
+//   c. tanh, bf16, into LDS hs[128 samples][128 ch] (aliasing xs; rows padded by 16 bytes);
+//   d. heads as out[16][16 samples] 16x16x32 MFMAs (rows 0..A-1 action logits, row A the value), wave w on its 32 samples;
+//   e. a sample's 16 outputs sit in 4 lanes (lane, +16, +32, +48): masked log-softmax (logits + (mask - 1) * 1e9,
+//      agent_network.py:66-75), entropy, inverse-CDF sampling with one Philox4x32-10 uniform per sample, log-prob.
+#define HEAD_TILE 128
+#define HEAD_XS_ROW (256 * 2 + 16)
+#define HEAD_HS_ROW (128 * 2 + 16)
+struct HeadArgs {
+    const uint16_t* y1;       // bf16 [B][256]
+    const u32x4_t* fc2_frag;  // [4 M-tiles][16 K-steps][64]
+    const float* fc2_bias;    // [128] (scaled)
+    const u32x4_t* head_frag; // [4 K-steps][64]
+    const float* head_bias;   // [16]
+    const float* mask;        // [B] decision: 1 => only actions 0..4, or NULL
+    const int32_t* given;     // [B] actions to evaluate instead of sampling, or NULL
+    int32_t* action;          // [B]
+    float* logprob;           // [B]
+    float* entropy;           // [B]
+    float* value;             // [B]
+    float* logits;            // [B][A] raw logits, or NULL
+    int64_t B;
+    int32_t A;
+    uint64_t seed, offset;
+};
+
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+__device__ __forceinline__ float xlane(float v, int mask) { return __shfl_xor(v, mask, WAVE); }
+
+__global__ void __launch_bounds__(256) k_policy_head(HeadArgs a) {
+    extern __shared__ uint32_t lds[];
+    uint8_t* xs = (uint8_t*)lds;  // stage a/b image; stage c/d image aliases it
+    uint8_t* hs = (uint8_t*)lds;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int n32 = lane & 31, hh = lane >> 5, n16 = lane & 15, g4 = lane >> 4;
+
+    u32x4_t w2[16], wh[4];
+#pragma unroll
+    for (int s = 0; s < 16; s++) w2[s] = a.fc2_frag[(wave * 16 + s) * WAVE + lane];
+#pragma unroll
+    for (int s = 0; s < 4; s++) wh[s] = a.head_frag[s * WAVE + lane];
+    f32x16_t bias2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) bias2[r] = a.fc2_bias[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    f32x4_t biash;
+#pragma unroll
+    for (int r = 0; r < 4; r++) biash[r] = a.head_bias[4 * g4 + r];
+
+    const int64_t n_tiles = (a.B + HEAD_TILE - 1) / HEAD_TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * HEAD_TILE;
+        // ---- a. tanh(fc1) of this wave's 32 rows -> xs
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const int r = 32 * wave + 2 * i + hh;  // row within the tile; lane n32 takes 16-byte chunk n32 of it
+            const int64_t srow = s0 + r;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (srow < a.B) v = *(const u32x4_t*)(a.y1 + srow * 256 + n32 * 8);
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = tanh2_pack(__uint_as_float(v[j] << 16), __uint_as_float(v[j] & 0xFFFF0000u));
+            *(u32x4_t*)(xs + r * HEAD_XS_ROW + n32 * 16) = o;
+        }
+        __syncthreads();
+        // ---- b. fc2: this wave's 32 channels x the tile's 128 samples
+        f32x16_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = bias2;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u32x4_t b = *(const u32x4_t*)(xs + (32 * t + n32) * HEAD_XS_ROW + (2 * s + hh) * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[s]), as_bf16x8(b), acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave is done reading xs: hs may overwrite it
+        // ---- c. tanh -> hs[sample][channel]
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32x2_t o;
+                o[0] = tanh2_pack(acc[t][4 * q], acc[t][4 * q + 1]);
+                o[1] = tanh2_pack(acc[t][4 * q + 2], acc[t][4 * q + 3]);
+                *(u32x2_t*)(hs + (32 * t + n32) * HEAD_HS_ROW + (32 * wave + 8 * q + 4 * hh) * 2) = o;
+            }
+        }
+        __syncthreads();
+        // ---- d. heads for this wave's 32 samples, e. distribution
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int r = 32 * wave + 16 * u + n16;
+            f32x4_t out = biash;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const u32x4_t b = *(const u32x4_t*)(hs + r * HEAD_HS_ROW + (4 * s + g4) * 16);
+                out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wh[s]), as_bf16x8(b), out, 0, 0, 0);
+            }
+            const int64_t smp = s0 + r;
+            const bool live = smp < a.B;
+            const float dec = (a.mask && live) ? a.mask[smp] : 0.0f;
+            float l[4], mx = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int o = 4 * g4 + q;
+                l[q] = (o < a.A) ? out[q] + ((dec == 1.0f && o >= 5) ? -1e9f : 0.0f) : -INFINITY;
+                mx = fmaxf(mx, l[q]);
+            }
+            mx = fmaxf(mx, xlane(mx, 16));
+            mx = fmaxf(mx, xlane(mx, 32));
+            float e[4], part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { e[q] = __expf(l[q] - mx); part += e[q]; }
+            float tot = part + xlane(part, 16);
+            tot += xlane(tot, 32);
+            const float logz = mx + __logf(tot);
+            float ent = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (4 * g4 + q < a.A) ent -= (e[q] / tot) * (l[q] - logz);
+            ent += xlane(ent, 16);
+            ent += xlane(ent, 32);
+            // inverse CDF over the outputs in index order: lanes g4 = 0..3 hold consecutive blocks of 4
+            const float p1 = xlane(part, 16), p2 = xlane(part, 32), p3 = xlane(p1, 32);  // partner sums: g4^1, g4^2, g4^3
+            float below = 0.0f;  // sum of the blocks with a smaller g4
+            if (g4 == 1) below = p1;            // block 0
+            else if (g4 == 2) below = p2 + p3;  // blocks 0 and 1
+            else if (g4 == 3) below = p1 + p2 + p3;
+            int act;
+            if (a.given) act = live ? a.given[smp] : 0;
+            else {
+                const float target = philox_uniform(a.seed, a.offset, (uint64_t)smp) * tot;
+                float c = below;
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { c += e[q]; cnt += (4 * g4 + q < a.A && c <= target) ? 1 : 0; }
+                cnt += __shfl_xor(cnt, 16, WAVE);
+                cnt += __shfl_xor(cnt, 32, WAVE);
+                const int last = (dec == 1.0f) ? min(4, a.A - 1) : a.A - 1;
+                act = min(cnt, last);
+            }
+            float lp = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (4 * g4 + q == act) lp = l[q] - logz;
+            lp += xlane(lp, 16);
+            lp += xlane(lp, 32);
+            if (live) {
+                if (g4 == 0) {
+                    a.action[smp] = act;
+                    a.logprob[smp] = lp;
+                    a.entropy[smp] = ent;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int o = 4 * g4 + q;
+                    if (o == a.A) a.value[smp] = out[q];
+                    if (a.logits && o < a.A) a.logits[smp * a.A + o] = out[q];
+                }
+            }
+        }
+        __syncthreads();  // hs is free again
+    }
+}
+
 static thread_local char g_perr[256];
 extern "C" const char* ctf_policy_last_error(void) { return g_perr; }
 static int pfail(const char* msg) {
@@ -359,6 +544,44 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
         if (err == hipSuccess) hipLaunchKernelGGL(k_policy_features<0>, dim3(blocks), dim3(wpb * WAVE), sh, st, a);
     }
     if (err == hipSuccess) err = hipGetLastError();
+    if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err != hipSuccess) return pfail(hipGetErrorString(err));
+    return 0;
+}
+
+extern "C" int ctf_policy_head(const uint16_t* fc1_out_dev, int64_t n_samples, const void* fc2_frag_dev, const float* fc2_bias_dev,
+                               const void* head_frag_dev, const float* head_bias_dev, const float* mask_decision_dev,
+                               const int32_t* given_action_dev, int32_t n_actions, uint64_t seed, uint64_t offset,
+                               int32_t* action_dev, float* logprob_dev, float* entropy_dev, float* value_dev, float* logits_dev,
+                               int32_t device_id, void* stream) {
+    if (!fc1_out_dev || !fc2_frag_dev || !fc2_bias_dev || !head_frag_dev || !head_bias_dev || !action_dev || !logprob_dev ||
+        !entropy_dev || !value_dev)
+        return pfail("null argument");
+    if (n_samples < 1) return pfail("n_samples must be >= 1");
+    if (n_actions < 1 || n_actions > 15) return pfail("n_actions outside 1..15");
+    if ((uintptr_t)fc1_out_dev & 15) return pfail("fc1_out_dev must be 16-byte aligned");
+    HeadArgs a;
+    a.y1 = fc1_out_dev; a.fc2_frag = (const u32x4_t*)fc2_frag_dev; a.fc2_bias = fc2_bias_dev;
+    a.head_frag = (const u32x4_t*)head_frag_dev; a.head_bias = head_bias_dev;
+    a.mask = mask_decision_dev; a.given = given_action_dev;
+    a.action = action_dev; a.logprob = logprob_dev; a.entropy = entropy_dev; a.value = value_dev; a.logits = logits_dev;
+    a.B = n_samples; a.A = n_actions; a.seed = seed; a.offset = offset;
+    int dev_prev = 0;
+    if (hipGetDevice(&dev_prev) != hipSuccess) return pfail("hipGetDevice failed");
+    if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
+    hipDeviceProp_t prop;
+    hipError_t err = hipGetDeviceProperties(&prop, device_id);
+    if (err == hipSuccess) {
+        const size_t sh = (size_t)HEAD_TILE * HEAD_XS_ROW;  // 66 KB: the stage a/b image; the stage c/d image is smaller
+        static_assert(HEAD_TILE * HEAD_XS_ROW >= HEAD_TILE * HEAD_HS_ROW, "hs aliases xs");
+        err = hipFuncSetAttribute((const void*)k_policy_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) {
+            const int64_t tiles = (n_samples + HEAD_TILE - 1) / HEAD_TILE;
+            const int64_t cap = (int64_t)prop.multiProcessorCount * 2;
+            hipLaunchKernelGGL(k_policy_head, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(256), sh, (hipStream_t)stream, a);
+            err = hipGetLastError();
+        }
+    }
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
     if (err != hipSuccess) return pfail(hipGetErrorString(err));
     return 0;

@@ -9,9 +9,10 @@ through the stock ``forward`` keeps working) and adds an inference path that nev
 
 * conv1 -> tanh -> conv2 -> tanh -> flatten ++ metadata: ``ctf_policy_features`` (include/ctf_policy.h,
   csrc/ctf_policy.hip), one wave per agent, activations in LDS, bf16 MFMA with float32 accumulation;
-* fc1 -> tanh -> fc2 -> tanh: bf16 GEMMs (hipBLASLt through torch) on the kernel's activation matrix — fc1's weight
-  columns are permuted once to the order the kernel writes;
-* heads, mask rule ``logits + (mask - 1) * 1e9`` (agent_network.py:66-75) and sampling in float32.
+* fc1: one bf16 GEMM (hipBLASLt through torch) on the kernel's activation matrix — fc1's weight columns are permuted once
+  to the order the kernel writes;
+* tanh -> fc2 -> tanh -> heads -> mask rule ``logits + (mask - 1) * 1e9`` (agent_network.py:66-75) -> sampling, log-prob,
+  entropy: ``ctf_policy_head``, one fused MFMA kernel (bf16 operands, float32 accumulation and distribution math).
 
 Numerics: bf16 operands, float32 accumulation; against the float32 reference network the logits / values differ by a few
 1e-2 (tests/test_gpu_policy_native.py states the tolerance).  ``prepare()`` must be called again after the parameters
@@ -22,7 +23,6 @@ import math
 
 import numpy as np
 import torch
-from torch.distributions.categorical import Categorical
 
 from . import _abi
 from .policy import CtfPolicy
@@ -68,35 +68,63 @@ def act_column_order(grid_size, meta_len):
     return src
 
 
+def tail_fragments(fc2_w, fc2_b, action_w, action_b, value_w, value_b):
+    """fc2 / head parameters -> the fused tail kernel's operands (include/ctf_policy.h, ctf_policy_head): bf16 MFMA
+    A-fragments (fc2 scaled by 2 log2(e): its output only feeds a tanh) and float32 biases."""
+    w2 = np.asarray(fc2_w, np.float64) * _TWO_LOG2E  # [128, 256]
+    if w2.shape != (128, 256):
+        raise ValueError("the fused tail is built for fc1 -> 256 -> fc2 -> 128 (agent_network.py:15-16)")
+    lane, j = np.arange(64), np.arange(8)
+    f2 = np.zeros((4, 16, 64, 8), np.float32)
+    for w in range(4):
+        for s in range(16):
+            f2[w, s] = w2[(32 * w + (lane & 31))[:, None], 16 * s + 8 * (lane >> 5)[:, None] + j[None, :]]
+    n_actions = np.asarray(action_w).shape[0]
+    if n_actions > 15:
+        raise ValueError("at most 15 actions")
+    wh = np.zeros((16, 128), np.float64)
+    wh[:n_actions] = np.asarray(action_w, np.float64)
+    wh[n_actions] = np.asarray(value_w, np.float64).reshape(-1)
+    fh = np.zeros((4, 64, 8), np.float32)
+    for s in range(4):
+        fh[s] = wh[(lane & 15)[:, None], 32 * s + 8 * (lane >> 4)[:, None] + j[None, :]]
+    bh = np.zeros(16, np.float32)
+    bh[:n_actions] = np.asarray(action_b, np.float32)
+    bh[n_actions] = np.asarray(value_b, np.float32).reshape(-1)[0]
+    return f2, (np.asarray(fc2_b, np.float64) * _TWO_LOG2E).astype(np.float32), fh, bh
+
+
 class CtfPolicyNative(CtfPolicy):
-    def __init__(self, n_actions, n_channels, grid_size, metadata_size):
+    def __init__(self, n_actions, n_channels, grid_size, metadata_size, seed=None):
         super().__init__(n_actions, n_channels, grid_size, metadata_size, compute_dtype=torch.bfloat16)
         self.grid_size, self.metadata_size, self.n_channels = grid_size, metadata_size, n_channels
         self._prep = None
+        self._seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)  # Philox key of the action sampler
+        self._calls = 0                                                                    # ... and its running offset
 
-    # -- weights in the kernel's / the GEMMs' layouts ----------------------------------------------
+    # -- weights in the kernels' / the GEMM's layouts ----------------------------------------------
     def prepare(self):
         dev = self.conv1.weight.device
         if dev.type != "cuda":
             raise _abi.CtfLibraryError("CtfPolicyNative runs on a HIP device only (there is no CPU fallback)")
         lib = _abi.load_library()
         with torch.no_grad():
-            f1, b1, f2, b2 = conv_fragments(self.conv1.weight.float().cpu().numpy(), self.conv1.bias.float().cpu().numpy(),
-                                            self.conv2.weight.float().cpu().numpy(), self.conv2.bias.float().cpu().numpy())
+            cpu = lambda t: t.detach().float().cpu().numpy()
+            f1, b1, f2, b2 = conv_fragments(cpu(self.conv1.weight), cpu(self.conv1.bias), cpu(self.conv2.weight), cpu(self.conv2.bias))
+            t2, tb2, th, tbh = tail_fragments(cpu(self.fc2.weight), cpu(self.fc2.bias), cpu(self.action_head.weight),
+                                              cpu(self.action_head.bias), cpu(self.value_head.weight), cpu(self.value_head.bias))
             bf = torch.bfloat16
             order = act_column_order(self.grid_size, self.metadata_size)
-            w = self.fc1.weight.float()
+            w = self.fc1.weight.float() * _TWO_LOG2E  # fc1's output only feeds a tanh: same scaling as the conv stages
             fc1 = torch.zeros((w.shape[0], len(order)), dtype=torch.float32, device=dev)
             keep = torch.from_numpy(order >= 0).to(dev)
             fc1[:, keep] = w[:, torch.from_numpy(order[order >= 0]).to(dev)]
+            up = lambda a, dt=None: (torch.from_numpy(a).to(dev) if dt is None else torch.from_numpy(a).to(dev).to(dt)).contiguous()
             self._prep = dict(
                 lib=lib, kp=len(order),
-                f1=torch.from_numpy(f1).to(dev).to(bf).contiguous(), b1=torch.from_numpy(b1).to(dev),
-                f2=torch.from_numpy(f2).to(dev).to(bf).contiguous(), b2=torch.from_numpy(b2).to(dev),
-                fc1_w=fc1.to(bf).contiguous(), fc1_b=self.fc1.bias.to(bf),
-                fc2_w=self.fc2.weight.to(bf).contiguous(), fc2_b=self.fc2.bias.to(bf),
-                head_w=torch.cat((self.action_head.weight, self.value_head.weight), dim=0).float().t().contiguous(),
-                head_b=torch.cat((self.action_head.bias, self.value_head.bias), dim=0).float(),
+                f1=up(f1, bf), b1=up(b1), f2=up(f2, bf), b2=up(b2),
+                fc1_w=fc1.to(bf).contiguous(), fc1_b=(self.fc1.bias.float() * _TWO_LOG2E).to(bf),
+                t2=up(t2, bf), tb2=up(tb2), th=up(th, bf), tbh=up(tbh),
             )
             assert lib.ctf_policy_act_stride(self.grid_size, self.metadata_size) == len(order)
         return self
@@ -131,22 +159,46 @@ class CtfPolicyNative(CtfPolicy):
             raise _abi.CtfLibraryError("ctf_policy_features: " + (p["lib"].ctf_policy_last_error() or b"").decode())
         return out
 
+    def _tail(self, feats, mask=None, given=None, want_logits=False):
+        """fc1 (bf16 GEMM) then the fused tail -> (action int32, logprob, entropy, value, logits or None), each [B]."""
+        p = self._ready()
+        y1 = torch.nn.functional.linear(feats, p["fc1_w"], p["fc1_b"])  # pre-activation, scaled by 2 log2(e)
+        return self._head(y1, mask, given, want_logits)
+
+    def _head(self, y1, mask=None, given=None, want_logits=False):
+        """ctf_policy_head on fc1's scaled pre-activation y1 (bf16 [B, 256])."""
+        p = self._ready()
+        B, dev = y1.shape[0], y1.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        action = torch.empty(B, dtype=torch.int32, device=dev)
+        logprob, entropy, value = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32)
+        logits = torch.empty((B, self.n_actions), **f32) if want_logits else None
+        if mask is not None:
+            mask = mask.reshape(-1).to(torch.float32).contiguous()
+            if mask.numel() != B:
+                raise ValueError("masking_decision_tensor must have one entry per sample")
+        if given is not None:
+            given = given.reshape(-1).to(torch.int32).contiguous()
+        self._calls += 1
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        rc = p["lib"].ctf_policy_head(
+            ptr(y1), B, ptr(p["t2"]), ptr(p["tb2"]), ptr(p["th"]), ptr(p["tbh"]), ptr(mask), ptr(given), self.n_actions,
+            C.c_uint64(self._seed), C.c_uint64(self._calls), ptr(action), ptr(logprob), ptr(entropy), ptr(value), ptr(logits),
+            dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise _abi.CtfLibraryError("ctf_policy_head: " + (p["lib"].ctf_policy_last_error() or b"").decode())
+        return action, logprob, entropy, value, logits
+
     def trunk_from_codes(self, codes, meta, agent_idx):
         """-> (value [B, 1], logits [B, A]) float32, B = len(agent_idx) * E, agent-major."""
-        p = self._ready()
-        x = self.features_from_codes(codes, meta, agent_idx)
-        x = torch.tanh_(torch.nn.functional.linear(x, p["fc1_w"], p["fc1_b"]))
-        x = torch.tanh_(torch.nn.functional.linear(x, p["fc2_w"], p["fc2_b"]))
-        y = torch.addmm(p["head_b"], x.float(), p["head_w"])
-        return y[:, self.n_actions:], y[:, :self.n_actions]
+        out = self._tail(self.features_from_codes(codes, meta, agent_idx), want_logits=True,
+                         given=torch.zeros(len(agent_idx) * codes.shape[0], dtype=torch.int32, device=codes.device))
+        return out[3].reshape(-1, 1), out[4]
 
     def act_from_codes(self, codes, meta, agent_idx, masking_decision_tensor, action=None):
-        """get_action_and_value (agent_network.py:63-81) for agents ``agent_idx`` of every env, from the compact observation."""
-        value, logits = self.trunk_from_codes(codes, meta, agent_idx)
-        decision = masking_decision_tensor.reshape(-1, 1).to(logits.dtype)
-        mask = torch.where(decision == 1, self.mask_5.unsqueeze(0), torch.ones_like(logits))
-        logits = logits + (mask - 1.0) * 1e9
-        dist = Categorical(logits=logits)
-        if action is None:
-            action = dist.sample()
-        return action, dist.log_prob(action), dist.entropy(), value
+        """get_action_and_value (agent_network.py:63-81) for agents ``agent_idx`` of every env, from the compact observation:
+        -> (action int32 [B], log_prob [B], entropy [B], value [B, 1]).  Sampling: inverse CDF of the masked softmax with one
+        Philox4x32-10 uniform per sample, keyed by this module's seed and call count."""
+        act, logprob, entropy, value, _ = self._tail(self.features_from_codes(codes, meta, agent_idx), mask=masking_decision_tensor,
+                                                     given=action)
+        return act, logprob, entropy, value.reshape(-1, 1)

@@ -125,6 +125,72 @@ def test_native_inference_is_close_to_the_reference_agent_and_respects_the_mask(
         assert np.abs(back(logits) - l2.cpu().numpy()).max() < 0.15
 
 
+def _emulate_tail(net, y1):
+    """float64 evaluation of ctf_policy_head's arithmetic on y1 = bf16 fc1 output (scaled): -> (logits [B, A], value [B])."""
+    t = lambda z: 1.0 - 2.0 / (torch.exp2(z) + 1.0)
+    cpu = lambda p: p.detach().cpu().double()
+    x = bf16(t(y1.cpu().double()))
+    z2 = x @ bf16(cpu(net.fc2.weight) * S).T + (cpu(net.fc2.bias) * S).float().double()
+    h2 = bf16(t(z2))
+    logits = h2 @ bf16(cpu(net.action_head.weight)).T + cpu(net.action_head.bias).float().double()
+    value = h2 @ bf16(cpu(net.value_head.weight)).T + cpu(net.value_head.bias).float().double()
+    return logits, value.reshape(-1)
+
+
+def test_fused_tail_matches_its_emulation_and_torch_distribution_math():
+    net = fill_(native.CtfPolicyNative(9, 14, 15, 22, seed=7)).cuda()
+    B = 300  # two full tiles of 128 and a ragged one
+    g = torch.Generator().manual_seed(1)
+    y1 = (torch.randn((B, 256), generator=g) * 2.0).to(torch.bfloat16).cuda()
+    want_logits, want_value = _emulate_tail(net, y1)
+    p = net._ready()
+    lib = p["lib"]
+    import ctypes as C
+
+    def head(mask=None, given=None, offset=1):
+        f32 = dict(dtype=torch.float32, device="cuda")
+        action = torch.empty(B, dtype=torch.int32, device="cuda")
+        lp, ent, val, logits = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32), torch.empty((B, 9), **f32)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        rc = lib.ctf_policy_head(ptr(y1), B, ptr(p["t2"]), ptr(p["tb2"]), ptr(p["th"]), ptr(p["tbh"]), ptr(mask), ptr(given), 9,
+                                 C.c_uint64(7), C.c_uint64(offset), ptr(action), ptr(lp), ptr(ent), ptr(val), ptr(logits), 0,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.ctf_policy_last_error()
+        torch.cuda.synchronize()
+        return action, lp, ent, val, logits
+
+    mask = (torch.arange(B, device="cuda") % 3 == 0).float()
+    action, lp, ent, val, logits = head(mask)
+    assert float((logits.cpu().double() - want_logits).abs().max()) < 5e-3  # bf16 rounding flips of the hidden layer
+    assert float((val.cpu().double() - want_value).abs().max()) < 5e-3
+    assert float((logits.cpu().double() - want_logits).abs().mean()) < 2e-4
+    masked = logits + (torch.where(mask[:, None] == 1, net.mask_5[None, :], torch.ones_like(logits)) - 1.0) * 1e9
+    dist = torch.distributions.Categorical(logits=masked)
+    assert bool((action >= 0).all()) and bool((action < 9).all()) and bool((action[mask == 1] < 5).all())
+    assert torch.allclose(lp, dist.log_prob(action.long()), atol=1e-4)
+    assert torch.allclose(ent, dist.entropy(), atol=1e-4)
+    # evaluating given actions: the reference's `action=` argument
+    given = (torch.arange(B, device="cuda") % 5).to(torch.int32)
+    a2, lp2, ent2, val2, _ = head(mask, given)
+    assert torch.equal(a2, given) and torch.allclose(lp2, dist.log_prob(given.long()), atol=1e-4) and torch.equal(val2, val)
+    # same key and counter: the same draw; another counter: another draw
+    assert torch.equal(head(mask, offset=1)[0], action) and not torch.equal(head(mask, offset=2)[0], action)
+
+
+def test_fused_tail_samples_the_softmax():
+    net = fill_(native.CtfPolicyNative(9, 14, 15, 22, seed=11)).cuda()
+    B = 1 << 17
+    row = (torch.randn((1, 256), generator=torch.Generator().manual_seed(3)) * 0.7).to(torch.bfloat16)
+    y1 = row.expand(B, 256).contiguous().cuda()
+    for decision in (0.0, 1.0):
+        mask = torch.full((B,), decision, device="cuda")
+        action, lp, ent, val, logits = net._head(y1, mask=mask, want_logits=True)
+        masked = logits[0] + ((net.mask_5 if decision == 1.0 else torch.ones_like(net.mask_5)) - 1.0) * 1e9
+        probs = torch.softmax(masked, dim=0)
+        freq = torch.bincount(action.long(), minlength=9).float() / B
+        assert float((freq - probs).abs().max()) < 6e-3, (freq, probs)  # ~4 sigma at B = 131072
+
+
 def test_native_path_fails_loudly_off_gpu():
     net = native.CtfPolicyNative(9, 14, 15, 22)
     with pytest.raises(pkg._abi.CtfLibraryError):

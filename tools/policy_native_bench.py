@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stage timings of the native policy path on the arena shape: observe_codes, ctf_policy_features, fc1, fc2, heads, sampling.
+"""Stage timings of the native policy path on the arena shape: observe_codes, ctf_policy_features, fc1, ctf_policy_head.
 
     python tools/policy_native_bench.py [envs]        (8 agents per env => B = 8 * envs samples)
 """
@@ -49,11 +49,9 @@ def main():
         out["features"] = timed(lambda: net.features_from_codes(codes, meta, sel, out=feats))
         F = torch.nn.functional
         out["fc1"] = timed(lambda: F.linear(feats, p["fc1_w"], p["fc1_b"]))
-        x1 = torch.tanh_(F.linear(feats, p["fc1_w"], p["fc1_b"]))
-        out["fc1_tanh"] = timed(lambda: torch.tanh_(x1))
-        out["fc2"] = timed(lambda: F.linear(x1, p["fc2_w"], p["fc2_b"]))
-        x2 = torch.tanh_(F.linear(x1, p["fc2_w"], p["fc2_b"]))
-        out["heads_fp32"] = timed(lambda: torch.addmm(p["head_b"], x2.float(), p["head_w"]))
+        y1 = F.linear(feats, p["fc1_w"], p["fc1_b"])
+        mask1 = torch.ones(B, device="cuda")
+        out["head"] = timed(lambda: net._head(y1, mask=mask1))
         out["trunk_from_codes"] = timed(lambda: net.trunk_from_codes(codes, meta, sel))
         mask = torch.ones(B, device="cuda")
         out["act_from_codes"] = timed(lambda: net.act_from_codes(codes, meta, sel, mask))
