@@ -15,8 +15,8 @@ through the stock ``forward`` keeps working) and adds an inference path that nev
   entropy: ``ctf_policy_head``, one fused MFMA kernel (bf16 operands, float32 accumulation and distribution math).
 
 Numerics: bf16 operands, float32 accumulation; against the float32 reference network the logits / values differ by a few
-1e-2 (tests/test_gpu_policy_native.py states the tolerance).  ``prepare()`` must be called again after the parameters
-change (it is called lazily on first use).
+1e-2 (tests/test_gpu_policy_native.py states the tolerance).  The kernel-side copies of the weights are rebuilt by
+``prepare()``; it runs by itself on first use and whenever a parameter was updated in place or moved since.
 """
 import ctypes as C
 import math
@@ -121,7 +121,7 @@ class CtfPolicyNative(CtfPolicy):
             fc1[:, keep] = w[:, torch.from_numpy(order[order >= 0]).to(dev)]
             up = lambda a, dt=None: (torch.from_numpy(a).to(dev) if dt is None else torch.from_numpy(a).to(dev).to(dt)).contiguous()
             self._prep = dict(
-                lib=lib, kp=len(order),
+                lib=lib, kp=len(order), stamp=self._stamp(),
                 f1=up(f1, bf), b1=up(b1), f2=up(f2, bf), b2=up(b2),
                 fc1_w=fc1.to(bf).contiguous(), fc1_b=(self.fc1.bias.float() * _TWO_LOG2E).to(bf),
                 t2=up(t2, bf), tb2=up(tb2), th=up(th, bf), tbh=up(tbh),
@@ -129,8 +129,12 @@ class CtfPolicyNative(CtfPolicy):
             assert lib.ctf_policy_act_stride(self.grid_size, self.metadata_size) == len(order)
         return self
 
+    def _stamp(self):
+        # in-place updates (optimiser steps, load_state_dict) bump a tensor's _version; .to() / .cuda() replace the storage
+        return tuple((q.data_ptr(), q._version) for q in self.parameters())
+
     def _ready(self):
-        if self._prep is None:
+        if self._prep is None or self._prep["stamp"] != self._stamp():
             self.prepare()
         return self._prep
 

@@ -191,6 +191,23 @@ def test_fused_tail_samples_the_softmax():
         assert float((freq - probs).abs().max()) < 6e-3, (freq, probs)  # ~4 sigma at B = 131072
 
 
+def test_kernel_side_weights_follow_parameter_updates():
+    z, grids, metas, n = _golden()
+    T = grids.shape[0] // n
+    net = fill_(native.CtfPolicyNative(9, grids.shape[1], grids.shape[2], metas.shape[1])).cuda()
+    codes = torch.tensor(encode(grids).reshape(T, n, 15, 15), device="cuda")
+    meta = torch.tensor(metas.reshape(T, n, -1), device="cuda")
+    v0, l0 = net.trunk_from_codes(codes, meta, [0])
+    opt = torch.optim.SGD(net.parameters(), lr=0.5)
+    for q in net.parameters():
+        q.grad = torch.ones_like(q) * 0.01
+    opt.step()  # in place: no explicit prepare()
+    v1, l1 = net.trunk_from_codes(codes, meta, [0])
+    assert not torch.equal(l0, l1)
+    v2, l2 = net(torch.tensor(grids[0::n], device="cuda"), torch.tensor(metas[0::n], device="cuda"))  # the stock forward, same weights
+    assert float((l1 - l2).abs().max()) < 0.15
+
+
 def test_native_path_fails_loudly_off_gpu():
     net = native.CtfPolicyNative(9, 14, 15, 22)
     with pytest.raises(pkg._abi.CtfLibraryError):
