@@ -151,6 +151,16 @@ def main():
     elapsed = sh.max_over_ranks(elapsed, device, world if not use_dist else max(world, 2))
     status = vec.status()
 
+    # secondary figure, outside the timed region: the same env-step with the observation in compact form
+    # (ctf_observe_codes: one byte per cell instead of C one-hot bytes — what the GPU policy path consumes)
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    for t in range(K):
+        vec.step(actions[W + t], auto_reset=True)
+        vec.observe_codes()
+    torch.cuda.synchronize()
+    compact_rate = E * K / (time.perf_counter() - tc)
+
     step_all = np.array([e[0].elapsed_time(e[1]) for e in ev])
     obs_all = np.array([e[1].elapsed_time(e[2]) for e in ev])
     step_ms, obs_ms = float(step_all.mean()), float(obs_all.mean())
@@ -199,6 +209,8 @@ def main():
                                        "k_observe": [float(x) for x in np.percentile(obs_all, [10, 50, 90])]},
             "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (step_ms * 1e-3) / 1e9,
             "device_status_bits": status,
+            "compact_observation": {"env_steps_per_s_per_gpu": compact_rate, "obs_bytes_per_env": N * G * G + N * (2 * N + 6) * 2,
+                                    "note": "step() + observe_codes(); not the headline metric (the reference's consumers take the one-hot planes)"},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, kwargs)

@@ -210,8 +210,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         const int T1 = (P1 + 15) >> 4;
         int x1 = x1_0, cell1 = y1_0 * G + x1_0;
         // two tiles per pass: two independent accumulation chains keep the MFMA pipe and the LDS busy within one wave
+        int t = 0;
 #pragma unroll 1
-        for (int t = 0; t < T1; t += 2) {
+        for (; t + 1 < T1; t += 2) {
             const uint8_t* base_a = h0 + ((POL_ABLATE & 8) ? 0 : cell1 * 16);
             x1 += dx1;
             cell1 += dy1 * G + dx1;
@@ -232,11 +233,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             o[0] = tanh2_pack(acc_a[0], acc_a[1]);
             o[1] = tanh2_pack(acc_a[2], acc_a[3]);
             *(u32x2_t*)(h1w + 16 * t * 16) = o;  // rows up to 16 * T1 exist
-            if (t + 1 < T1) {
-                o[0] = tanh2_pack(acc_b[0], acc_b[1]);
-                o[1] = tanh2_pack(acc_b[2], acc_b[3]);
-                *(u32x2_t*)(h1w + 16 * (t + 1) * 16) = o;
+            o[0] = tanh2_pack(acc_b[0], acc_b[1]);
+            o[1] = tanh2_pack(acc_b[2], acc_b[3]);
+            *(u32x2_t*)(h1w + 16 * (t + 1) * 16) = o;
+        }
+        if (t < T1) {  // odd tile count: the last one alone
+            const uint8_t* base_a = h0 + ((POL_ABLATE & 8) ? 0 : cell1 * 16);
+            f32x4_t acc_a = bias1;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const u32x4_t ba = *(const u32x4_t*)(base_a + off1[q]);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w1[q]), as_bf16x8(ba), acc_a, 0, 0, 0);
             }
+            u32x2_t o;
+            o[0] = tanh2_pack(acc_a[0], acc_a[1]);
+            o[1] = tanh2_pack(acc_a[2], acc_a[3]);
+            *(u32x2_t*)(h1w + 16 * t * 16) = o;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
@@ -259,13 +271,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(ba), acc_a, 0, 0, 0);
                 acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(bb), acc_b, 0, 0, 0);
             }
+            // one address per pass: the four channel groups of a lane sit (2 q - 3) * P2 * 4 elements around `mid`
+            uint16_t* mid = arow + ((3 + hh) * P2 + pa) * 4;
             if ((POL_ABLATE & 1) ? (acc_a[0] == 12345.0f && acc_b[5] == 1.0f) : (pa < P2)) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     u32x2_t o;
                     o[0] = tanh2_pack(acc_a[4 * q], acc_a[4 * q + 1]);
                     o[1] = tanh2_pack(acc_a[4 * q + 2], acc_a[4 * q + 3]);
-                    *(u32x2_t*)(arow + ((2 * q + hh) * P2 + pa) * 4) = o;
+                    *(u32x2_t*)(mid + (2 * q - 3) * P2 * 4) = o;
                 }
             }
             if ((POL_ABLATE & 1) ? (acc_b[0] == 12345.0f && acc_a[7] == 1.0f) : (pb < P2)) {
@@ -274,7 +288,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                     u32x2_t o;
                     o[0] = tanh2_pack(acc_b[4 * q], acc_b[4 * q + 1]);
                     o[1] = tanh2_pack(acc_b[4 * q + 2], acc_b[4 * q + 3]);
-                    *(u32x2_t*)(arow + ((2 * q + hh) * P2 + pb) * 4) = o;
+                    *(u32x2_t*)(mid + (2 * q - 3) * P2 * 4 + 32 * 4) = o;
                 }
             }
         }

@@ -77,3 +77,56 @@ def test_expand_codes_numpy_and_torch_agree_with_the_definition():
     codes = ((obs[:, :, 1:] * np.arange(1, c, dtype=np.uint8).reshape(1, 1, c - 1, 1, 1)).sum(axis=2) | (obs[:, :, 0] << 7)).astype(np.uint8)
     assert np.array_equal(pkg.expand_codes(codes, c), obs)
     assert np.array_equal(pkg.expand_codes(torch.from_numpy(codes), c).numpy(), obs)
+
+
+def test_policy_kernel_operands_follow_the_documented_lane_maps():
+    """policy_native's host-side packing (no GPU): rebuilding the weight matrices from the MFMA A-fragments with the lane
+    maps of include/ctf_policy.h gives back the scaled weights; fc1's column permutation is a bijection onto the
+    reference's flatten order."""
+    import math
+
+    native = importlib.import_module("marl-ctf-development_amd.policy_native")
+    rng = np.random.default_rng(0)
+    c_in = 14
+    w1, b1 = rng.standard_normal((16, c_in, 3, 3)), rng.standard_normal(16)
+    w2, b2 = rng.standard_normal((32, 16, 3, 3)), rng.standard_normal(32)
+    f1, fb1, f2, fb2 = native.conv_fragments(w1, b1, w2, b2)
+    s = 2.0 / math.log(2.0)
+    lane = np.arange(64)
+    for st in range(5):           # 16x16x32: lane holds A[row = lane & 15][k = 8 (lane >> 4) + j]; k = (tap pair, channel)
+        for l in lane:
+            for j in range(8):
+                k = 8 * (l >> 4) + j
+                tap, cin = 2 * st + k // 16, k % 16
+                want = w1[l & 15, cin, tap // 3, tap % 3] * s if (tap < 9 and cin < c_in) else 0.0
+                assert abs(f1[st, l, j] - want) < 1e-6
+    for tap in range(9):          # 32x32x16: lane holds A[row = lane & 31][k = 8 (lane >> 5) + j], k = input channel
+        for l in lane:
+            for j in range(8):
+                assert abs(f2[tap, l, j] - w2[l & 31, 8 * (l >> 5) + j, tap // 3, tap % 3] * s) < 1e-6
+    assert np.allclose(fb1, b1 * s) and np.allclose(fb2, b2 * s)
+
+    for g, m in ((15, 22), (11, 14), (7, 10)):
+        order = native.act_column_order(g, m)
+        p2 = (g - 4) ** 2
+        assert len(order) % 32 == 0 and len(order) >= 32 * p2 + m
+        real = order[order >= 0]
+        assert sorted(real.tolist()) == list(range(32 * p2 + m))          # every reference column exactly once
+        for c_, p_ in ((0, 0), (5, 3), (31, p2 - 1)):
+            assert order[((c_ // 4) * p2 + p_) * 4 + c_ % 4] == c_ * p2 + p_
+
+    wf2, bf2 = rng.standard_normal((128, 256)), rng.standard_normal(128)
+    wa, ba, wv, bv = rng.standard_normal((9, 128)), rng.standard_normal(9), rng.standard_normal((1, 128)), rng.standard_normal(1)
+    t2, tb2, th, tbh = native.tail_fragments(wf2, bf2, wa, ba, wv, bv)
+    for w in range(4):
+        for st in (0, 7, 15):
+            for l in (0, 17, 33, 63):
+                for j in range(8):
+                    assert abs(t2[w, st, l, j] - wf2[32 * w + (l & 31), 16 * st + 8 * (l >> 5) + j] * s) < 1e-6
+    head = np.zeros((16, 128))
+    head[:9], head[9] = wa, wv[0]
+    for st in range(4):
+        for l in lane:
+            for j in range(8):
+                assert abs(th[st, l, j] - head[l & 15, 32 * st + 8 * (l >> 4) + j]) < 1e-6
+    assert np.allclose(tb2, bf2 * s) and np.allclose(tbh[:9], ba) and np.allclose(tbh[9], bv[0]) and not tbh[10:].any()
