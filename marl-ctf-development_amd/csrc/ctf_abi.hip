@@ -18,7 +18,7 @@ extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint6
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
 extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
-extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint32_t, int, hipStream_t);
+extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
 
@@ -364,8 +364,7 @@ extern "C" int ctf_observe_codes(ctf_env* h, uint8_t* codes, uint16_t* meta, uin
     if (!codes && !meta) return CTF_OK;
     DeviceGuard guard(h->device);
     const uint32_t rev = resolve_reverse(h, reverse_mask);
-    if (codes) HIP_TRY(ctf_launch_observe_codes(h->d, h->p, codes, rev, h->n_cus, (hipStream_t)stream));
-    if (meta) HIP_TRY(ctf_launch_observe(h->d, h->p, nullptr, meta, rev, h->n_cus, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_observe_codes(h->d, h->p, codes, meta, rev, h->n_cus, (hipStream_t)stream));
     return CTF_OK;
 }
 

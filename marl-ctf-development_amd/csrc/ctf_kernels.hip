@@ -1085,30 +1085,55 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
 // G*G bytes: codes[e][i][d] = index of the tile plane that is 1 at cell d of agent i's view (0 = none), bit 7 = plane 0.
 // A policy that consumes the codes directly (ctf_policy.hip) never needs the 14x larger one-hot block.
 // Per env a wave builds the (viewer team, reversed?) code maps that are in use (at most 4) in LDS; every agent's row is
-// its map plus the own-position bit.  Per-wave LDS: [grid GS][rec RS][self cell u16[16]][maps 4 x GGp], GGp = GG rounded to 4.
-__host__ __device__ inline int codes_wave_bytes(int GS, int RS, int GG) { return GS + RS + 32 + 4 * ((GG + 3) & ~3); }
+// its map plus the own-position bit: an output dword is two aligned dwords of the map funnel-shifted (v_alignbyte_b32).
+// The metadata rows leave in the same launch.  Per-wave LDS: obs_build_env's metadata scratch ...
+// ... and the metadata scratch of obs_build_env when the launch also writes the metadata rows:
+// [rec RS][mvals 96][meta staging][meta LUT][grid GS][self cell u16[16]][maps 4 x (GGp + 4)]
+__host__ __device__ inline int codes_map_stride(int GG) { return ((GG + 3) & ~3) + 4; }  // + 4: the funnel read's second dword
+__host__ __device__ inline int codes_wave_bytes(int GS, int RS, int GG, int N, int M) {
+    return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_meta_lut_bytes(N, M) + GS + 32 + 4 * codes_map_stride(GG);
+}
 
 template <bool DWORDS>
-__global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ codes, uint32_t reverse_mask) {
+__global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ codes,
+                                                       uint16_t* __restrict__ meta, uint32_t reverse_mask) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const int wpb = blockDim.x / WAVE;
-    const int N = cfg.N, G = cfg.G, GG = cfg.GG, GGp = (GG + 3) & ~3;
-    uint8_t* wl = (uint8_t*)lds + wave * codes_wave_bytes(cfg.GS, cfg.RS, GG);
-    uint8_t* sgrid = wl;
-    uint8_t* srec = wl + cfg.GS;
-    uint16_t* selfc = (uint16_t*)(srec + cfg.RS);
+    const int N = cfg.N, M = cfg.M, G = cfg.G, GG = cfg.GG, MS = codes_map_stride(GG);
+    uint8_t* wl = (uint8_t*)lds + wave * codes_wave_bytes(cfg.GS, cfg.RS, GG, N, M);
+    uint8_t* srec = wl;
+    uint16_t* mv = (uint16_t*)(wl + cfg.RS);
+    uint16_t* mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
+    uint8_t* mlut = wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
+    uint8_t* sgrid = mlut + obs_meta_lut_bytes(N, M);
+    uint16_t* selfc = (uint16_t*)(sgrid + cfg.GS);
     uint8_t* maps = (uint8_t*)(selfc + 16);
     const ObsSlots slots = obs_slots(cfg, reverse_mask);
     uint32_t slot_pack = 0;  // 2 bits per agent
     for (int i = 0; i < N; i++) slot_pack |= (uint32_t)(cfg.team[i] * 2 + (int)((reverse_mask >> i) & 1u)) << (2 * i);
+    if (meta) obs_meta_lut(cfg, mlut, mv, lane);
     const int row = N * GG;
-    for (int e = blockIdx.x * wpb + wave; e < cfg.n_envs; e += gridDim.x * wpb) {
-        for (int w = lane; w < cfg.GS / 4; w += WAVE) ((uint32_t*)sgrid)[w] = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];
-        if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = ((const uint32_t*)(p.rec + (size_t)e * cfg.RS))[lane];
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+    const int GW = cfg.GS / 4;
+    const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
+    const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
+    // a wave's envs are a dependent chain of load -> build -> store: the next env's state is loaded while this one is built
+    uint32_t recw_n = 0, cells_n = 0;
+    if (e_first < cfg.n_envs) {
+        recw_n = ((const uint32_t*)(p.rec + (size_t)e_first * cfg.RS))[rec_lane];
+        cells_n = ((const uint32_t*)(p.grid + (size_t)e_first * cfg.GS))[grid_lane];
+    }
+    for (int e = e_first; e < cfg.n_envs; e += e_stride) {
+        const uint32_t recw = recw_n, cells = cells_n;
+        const int e_next = min(e + e_stride, cfg.n_envs - 1);
+        recw_n = ((const uint32_t*)(p.rec + (size_t)e_next * cfg.RS))[rec_lane];
+        cells_n = ((const uint32_t*)(p.grid + (size_t)e_next * cfg.GS))[grid_lane];
+        if (lane < GW) ((uint32_t*)sgrid)[lane] = cells;
+        for (int w = lane + WAVE; w < GW; w += WAVE) ((uint32_t*)sgrid)[w] = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16
+        // parks the record in LDS and, when asked for, writes this env's metadata rows
+        obs_build_env(cfg, p, e, recw, 0u, srec, mv, mstage, mlut, nullptr, slots, reverse_mask, lane, false, meta);
+        if (!codes) continue;
         if (lane < N) {
             const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
             const int r = ps[2 * lane], c = ps[2 * lane + 1];
@@ -1124,27 +1149,38 @@ __global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, ui
                 const uint32_t v = sgrid[src];
                 uint32_t code = (((v & 8u) ? (uint32_t)(lut >> 32) : (uint32_t)lut) >> (4 * (v & 7u))) & 15u;
                 if (v == 0 || code == CTF_TILE_NONE) code = 0;
-                maps[slot * GGp + d] = (uint8_t)code;
+                maps[slot * MS + d] = (uint8_t)code;
             }
         }
         __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
         __builtin_amdgcn_wave_barrier();
         uint8_t* out = codes + (size_t)e * row;
         for (int q = lane; q < (row + 3) / 4; q += WAVE) {
-            uint32_t word = 0;
+            const int f0 = 4 * q;
+            const int i0 = (int)fdiv((uint32_t)f0, cfg.div_gg_row), d0 = f0 - i0 * GG;
+            uint32_t word;
+            if (DWORDS && d0 + 3 < GG) {
+                // the four bytes lie in one agent's row: two aligned dwords of its map, funnel-shifted to d0
+                const uint32_t* m32 = (const uint32_t*)(maps + ((slot_pack >> (2 * i0)) & 3u) * MS);
+                word = __builtin_amdgcn_alignbyte(m32[(d0 >> 2) + 1], m32[d0 >> 2], (uint32_t)(d0 & 3));
+                const uint32_t sd = (uint32_t)((int)selfc[i0] - d0);
+                if (sd < 4u) word |= 0x80u << (8 * sd);
+                ((uint32_t*)out)[q] = word;
+            } else {
+                word = 0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int f = 4 * q + b;
-                if (f < row) {
-                    const int i = (int)fdiv((uint32_t)f, cfg.div_gg_row), d = f - i * GG;
-                    const uint32_t sl = (slot_pack >> (2 * i)) & 3u;
-                    uint32_t v = maps[sl * GGp + d];
-                    if (d == (int)selfc[i]) v |= 0x80u;
-                    if (DWORDS) word |= v << (8 * b);
-                    else out[f] = (uint8_t)v;
+                for (int b = 0; b < 4; b++) {
+                    const int f = f0 + b;
+                    if (f < row) {
+                        const int i = (d0 + b >= GG) ? i0 + 1 : i0, d = (d0 + b >= GG) ? d0 + b - GG : d0 + b;
+                        uint32_t v = maps[((slot_pack >> (2 * i)) & 3u) * MS + d];
+                        if (d == (int)selfc[i]) v |= 0x80u;
+                        if (DWORDS) word |= v << (8 * b);
+                        else out[f] = (uint8_t)v;
+                    }
                 }
+                if (DWORDS) ((uint32_t*)out)[q] = word;
             }
-            if (DWORDS) ((uint32_t*)out)[q] = word;
         }
         __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
         __builtin_amdgcn_wave_barrier();
@@ -1257,15 +1293,17 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     return hipGetLastError();
 }
-extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint32_t reverse_mask, int n_cus,
-                                               hipStream_t st) {
-    const int wpb = 4;
-    const size_t sh = (size_t)wpb * codes_wave_bytes(cfg.GS, cfg.RS, cfg.GG);
+extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint16_t* meta, uint32_t reverse_mask,
+                                               int n_cus, hipStream_t st) {
+    const int per_wave = codes_wave_bytes(cfg.GS, cfg.RS, cfg.GG, cfg.N, cfg.M);
+    int wpb = 4;
+    while (wpb > 1 && wpb * per_wave > 40 * 1024) wpb >>= 1;
+    const size_t sh = (size_t)wpb * per_wave;
     int blocks = (cfg.n_envs + wpb - 1) / wpb;
     if (blocks > n_cus * 8) blocks = n_cus * 8;
     const bool dwords = ((cfg.N * cfg.GG) % 4) == 0 && ((uintptr_t)codes % 4) == 0;
-    if (dwords) hipLaunchKernelGGL(k_observe_codes<true>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, reverse_mask);
-    else hipLaunchKernelGGL(k_observe_codes<false>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, reverse_mask);
+    if (dwords) hipLaunchKernelGGL(k_observe_codes<true>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, meta, reverse_mask);
+    else hipLaunchKernelGGL(k_observe_codes<false>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, meta, reverse_mask);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg& cfg, const DevPtrs& p, int32_t* metrics, int32_t* captures, int32_t* steps,

@@ -86,17 +86,27 @@ class BatchedRolloutCollector:
         return (action.reshape(k, E), logprob.reshape(k, E), value.reshape(k, E), grid.reshape((k, E) + tuple(obs.shape[2:])),
                 md.reshape(k, E, -1), mask.reshape(k, E))
 
-    def _policy_codes(self, net, codes, meta, idx, want_inputs=True):
-        """The same over the compact observation: the network reads the env's code bytes in place."""
-        torch = self.torch
-        E, k = self.vec.n_envs, idx.numel()
+    def _policy_codes(self, net, codes, meta, idx, agents, want_inputs=True):
+        """The same over the compact observation: the network reads the env's code bytes in place.  (`agents` = `idx` as a
+        host list: no device round trip per step.)"""
+        E, k = self.vec.n_envs, len(agents)
         mask = self.mask_flag.index_select(0, idx)[:, None].expand(-1, E).reshape(-1)
-        action, logprob, _, value = net.act_from_codes(codes, meta, idx.tolist(), mask)
+        action, logprob, _, value = net.act_from_codes(codes, meta, agents, mask)
         grid = md = None
-        if want_inputs:
-            grid = codes.index_select(1, idx).transpose(0, 1)
-            md = meta.index_select(1, idx).transpose(0, 1).to(torch.float32)
+        if want_inputs:  # views where the agents form a regular slice: the rollout buffer is then filled by ONE strided copy
+            sl = self._as_slice(agents)
+            grid = (codes[:, sl] if sl is not None else codes.index_select(1, idx)).transpose(0, 1)
+            md = (meta[:, sl] if sl is not None else meta.index_select(1, idx)).transpose(0, 1)
         return action.reshape(k, E), logprob.reshape(k, E), value.reshape(k, E), grid, md, mask.reshape(k, E)
+
+    @staticmethod
+    def _as_slice(v):
+        if len(v) == 1:
+            return slice(v[0], v[0] + 1)
+        step = v[1] - v[0]
+        if step > 0 and all(b - a == step for a, b in zip(v, v[1:])):
+            return slice(v[0], v[-1] + 1, step)
+        return None
 
     def joint_actions(self, agent, opponent, use_codes):
         """One decision of every agent of every env -> (what the trained team's policy returned, env actions int8 [E, N]):
@@ -104,8 +114,8 @@ class BatchedRolloutCollector:
         torch, vec = self.torch, self.vec
         if use_codes:
             codes, meta = vec.observe_codes()  # default reversal: team(i) == 1
-            trained = self._policy_codes(agent, codes, meta, self.trained_idx)
-            o_act = self._policy_codes(opponent, codes, meta, self.others_idx, want_inputs=False)[0]
+            trained = self._policy_codes(agent, codes, meta, self.trained_idx, self.trained)
+            o_act = self._policy_codes(opponent, codes, meta, self.others_idx, self.others, want_inputs=False)[0]
         else:
             obs, meta = vec.observe()
             trained = self._policy(agent, obs, meta, self.trained_idx)

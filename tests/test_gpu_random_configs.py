@@ -67,6 +67,9 @@ def test_random_config_matches_oracle(g, n, n_envs):
         mask = None if t % 16 else (1 << n) - 1 if t % 32 else 0  # non-default reversal flags now and then
         rewards, done = vec.step(acts, auto_reset=True, want_f64=True)
         obs, meta = vec.observe(reverse_mask=mask)
+        if t % 5 == 0:  # the compact observation carries the same planes (dword and byte store paths, every grid size)
+            codes, meta_c = vec.observe_codes(reverse_mask=mask)
+            assert torch.equal(pkg.expand_codes(codes, vec.N_CHANNELS), obs) and torch.equal(meta_c, meta), f"G={g} N={n} step {t}"
         a, r64, d = acts.cpu().numpy(), vec.rewards64.cpu().numpy(), done.cpu().numpy()
         o, m = obs.cpu().numpy(), meta.cpu().numpy().view(np.uint16)
         for e, r in enumerate(refs):
