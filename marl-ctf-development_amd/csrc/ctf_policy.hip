@@ -489,6 +489,16 @@ static int pfail(const char* msg) {
     return -1;
 }
 
+// compute units of a device, looked up once per device and thread (hipGetDeviceProperties is not free)
+static int policy_n_cus(int device_id) {
+    static thread_local int cus_of[64];
+    if (device_id >= 0 && device_id < 64 && cus_of[device_id]) return cus_of[device_id];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return 0;
+    if (device_id >= 0 && device_id < 64) cus_of[device_id] = prop.multiProcessorCount;
+    return prop.multiProcessorCount;
+}
+
 extern "C" int32_t ctf_policy_act_stride(int32_t grid_size, int32_t meta_len) {
     const int p2 = (grid_size - 4) * (grid_size - 4);
     return (32 * p2 + meta_len + 31) & ~31;
@@ -524,17 +534,11 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
     for (int p = 0; p < G2 * G2; p++)
         if ((int)(((uint32_t)p * a.inv_g2) >> 16) != p / G2) return pfail("internal: reciprocal of G-4 not exact");
 
+    const int n_cus = policy_n_cus(device_id);
+    if (!n_cus) return pfail("hipGetDeviceProperties failed");
     int dev_prev = 0;
     if (hipGetDevice(&dev_prev) != hipSuccess) return pfail("hipGetDevice failed");
     if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
-    hipDeviceProp_t prop;
-    static thread_local int cus_of[64];
-    int n_cus = (device_id >= 0 && device_id < 64) ? cus_of[device_id] : 0;
-    if (!n_cus) {
-        if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return pfail("hipGetDeviceProperties failed");
-        n_cus = prop.multiProcessorCount;
-        if (device_id >= 0 && device_id < 64) cus_of[device_id] = n_cus;
-    }
     const int per_wave = pol_h0_bytes(grid_size) + pol_h1_bytes(grid_size);
     int wpb = 4;
     while (wpb > 1 && wpb * per_wave > 64 * 1024) wpb >>= 1;
@@ -583,15 +587,15 @@ extern "C" int ctf_policy_head(const uint16_t* fc1_out_dev, int64_t n_samples, c
     int dev_prev = 0;
     if (hipGetDevice(&dev_prev) != hipSuccess) return pfail("hipGetDevice failed");
     if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
-    hipDeviceProp_t prop;
-    hipError_t err = hipGetDeviceProperties(&prop, device_id);
+    const int n_cus = policy_n_cus(device_id);
+    hipError_t err = n_cus ? hipSuccess : hipErrorInvalidDevice;
     if (err == hipSuccess) {
         const size_t sh = (size_t)HEAD_TILE * HEAD_XS_ROW;  // 66 KB: the stage a/b image; the stage c/d image is smaller
         static_assert(HEAD_TILE * HEAD_XS_ROW >= HEAD_TILE * HEAD_HS_ROW, "hs aliases xs");
         err = hipFuncSetAttribute((const void*)k_policy_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (err == hipSuccess) {
             const int64_t tiles = (n_samples + HEAD_TILE - 1) / HEAD_TILE;
-            const int64_t cap = (int64_t)prop.multiProcessorCount * 2;
+            const int64_t cap = (int64_t)n_cus * 2;
             hipLaunchKernelGGL(k_policy_head, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(256), sh, (hipStream_t)stream, a);
             err = hipGetLastError();
         }
