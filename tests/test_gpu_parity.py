@@ -183,6 +183,10 @@ def test_full_size_arena_properties_and_sample():
         # a team-1 agent's reversed view of the walls equals a team-0 agent's view rotated by 180 degrees
         wall = tiles.index(1) + 1
         assert bool((obs[:, 0, wall] == torch.flip(obs[:, 1, wall], dims=(1, 2))).all())
+        if t % 4 == 3:  # the compact observation of all 65 536 envs expands to the same 1.65 GB block
+            codes, _ = vec.observe_codes(meta=False)
+            for lo in range(0, E, 8192):
+                assert torch.equal(pkg.expand_codes(codes[lo:lo + 8192], vec.N_CHANNELS), obs[lo:lo + 8192]), (t, lo)
         a = acts[torch.from_numpy(sample).to(vec.device)].cpu().numpy()
         o = obs[torch.from_numpy(sample).to(vec.device)].cpu().numpy()
         m = meta[torch.from_numpy(sample).to(vec.device)].cpu().numpy().view(np.uint16)

@@ -191,6 +191,35 @@ def test_fused_tail_samples_the_softmax():
         assert float((freq - probs).abs().max()) < 6e-3, (freq, probs)  # ~4 sigma at B = 131072
 
 
+def test_full_size_batch_is_deterministic_and_matches_the_emulation_on_a_sample():
+    """BASELINE size: 65 536 arena envs x 8 agents = 524 288 samples (a 4.1 GB activation matrix: 64-bit offsets)."""
+    kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+    E = 65536
+    vec = pkg.VecGridworldCtf(E, device=0, **kw)
+    acts = torch.empty((E, 8), dtype=torch.int8, device="cuda")
+    for t in range(6):
+        vec.random_actions(acts, seed=5, step=t)
+        vec.step(acts)
+    codes, meta = vec.observe_codes()
+    net = fill_(native.CtfPolicyNative(9, vec.N_CHANNELS, 15, vec.META_LEN, seed=3)).cuda()
+    sel = list(range(8))
+    f1 = net.features_from_codes(codes, meta, sel)
+    f2 = net.features_from_codes(codes, meta, sel)
+    assert torch.equal(f1, f2) and bool(torch.isfinite(f1.float()).all())
+    rows = torch.tensor([0, 1, E - 1, E, 3 * E + 17, 8 * E - 1, 5 * E + 4242], device="cuda")  # row k * E + e
+    k, e = (rows // E).cpu(), (rows % E).cpu()
+    planes = torch.tensor(pkg.expand_codes(codes.cpu().numpy()[e, k], vec.N_CHANNELS))
+    want = emulate(net, planes, meta.cpu()[e, k])
+    assert float((unpermute(net, f1[rows]) - want).abs().max()) <= 2.0 ** -7
+    mask = torch.zeros(8 * E, device="cuda")
+    a1 = net.act_from_codes(codes, meta, sel, mask)
+    net._calls -= 1  # replay the same Philox counter
+    a2 = net.act_from_codes(codes, meta, sel, mask)
+    assert all(torch.equal(x, y) for x, y in zip(a1, a2))
+    assert int(a1[0].min()) >= 0 and int(a1[0].max()) <= 8 and bool(torch.isfinite(a1[1]).all())
+    vec.close()
+
+
 def test_kernel_side_weights_follow_parameter_updates():
     z, grids, metas, n = _golden()
     T = grids.shape[0] // n
