@@ -177,8 +177,11 @@ int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t rev
  *   codes_dev    uint8 [E][N][G][G] or NULL: low 7 bits = index of the plane that is 1 at this cell (0 = none of
  *                1..C-1), bit 7 = plane 0;  obs[e][i][k][r][c] == (k ? (codes & 127) == k : codes >> 7)
  *   meta_dev     as ctf_observe
+ *   selfcell_dev uint16 [E][N] or NULL: the cell index (row-major over G x G, after the flip) at which agent i's row has
+ *                bit 7 set — redundant with codes_dev, for consumers that treat a team's agents together
  * 1/C of the bytes of ctf_observe; what a GPU policy (include/ctf_policy.h) and a rollout buffer consume. */
-int ctf_observe_codes(ctf_env* env, uint8_t* codes_dev, uint16_t* meta_dev, uint32_t reverse_mask, void* stream);
+int ctf_observe_codes(ctf_env* env, uint8_t* codes_dev, uint16_t* meta_dev, uint16_t* selfcell_dev, uint32_t reverse_mask,
+                      void* stream);
 
 /* ctf_step immediately followed by ctf_observe in ONE launch (the rollout inner loop, ppo.py:59-98). */
 int ctf_step_observe(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev,

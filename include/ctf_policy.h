@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-/* Row length (in bf16 elements) of the activation matrix: 32 * (G-4)^2 + meta_len rounded up to a multiple of 32. */
+/* Row length (in bf16 elements) of the activation matrix: 32 * PP + meta_len rounded up to a multiple of 64, where
+ * PP = (G-4)^2 rounded up to a multiple of 32 (whole 128-byte lines per store instruction and per row). */
 int32_t ctf_policy_act_stride(int32_t grid_size, int32_t meta_len);
 
 /* act[k * n_envs + e][:] = features of agent agent_sel[k] of env e  (agent-major rows, the order
@@ -36,13 +37,21 @@ int32_t ctf_policy_act_stride(int32_t grid_size, int32_t meta_len);
  *   conv2_frag_dev   bf16 [9][64][8]: [tap][lane][j] = W2[out = lane & 31][in = 8 * (lane >> 5) + j][tap] * 2 log2(e)
  *   conv2_bias_dev   float [32]: conv2.bias * 2 log2(e)
  *   act_dev          bf16 [n_sel * n_envs][ctf_policy_act_stride()], 16-byte aligned.  Column of conv2 output channel c
- *                    at position p (row-major over (G-4)^2): ((c / 4) * P2 + p) * 4 + c % 4, P2 = (G-4)^2; then the
- *                    meta_len metadata values; then zeros.  (fc1.weight's columns are permuted to this order once.)
+ *                    at position p (row-major over (G-4)^2): ((c / 4) * PP + p) * 4 + c % 4; columns of positions
+ *                    (G-4)^2 .. PP-1 hold finite don't-care values (give them zero weight); at 32 * PP the meta_len
+ *                    metadata values; then don't-care padding.  (fc1.weight's columns are permuted to this order once.)
+ *   shared_view_selfcell_dev   NULL, or uint16 [n_envs][n_agents] from ctf_observe_codes (the cell of every agent's bit 7)
+ *                    together with the caller's guarantee that the selected agents see the same tile planes — same team
+ *                    and same reverse flag (standardise_state relabels by team, gridworld_ctf.py:981-988), so that their
+ *                    code rows differ only in bit 7.  The convolutions are then evaluated once per env and patched per
+ *                    agent (3 x 3 conv1 / 5 x 5 conv2 outputs around the own cell); results are bit-identical to the NULL
+ *                    path.  Honoured for n_sel <= 4 and G in {11, 15}, ignored otherwise.
  */
 int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* meta_dev, int32_t n_envs, int32_t n_agents,
                         int32_t grid_size, int32_t meta_len, const int32_t* agent_sel, int32_t n_sel,
                         const void* conv1_frag_dev, const float* conv1_bias_dev, const void* conv2_frag_dev,
-                        const float* conv2_bias_dev, uint16_t* act_dev, int32_t device_id, void* stream);
+                        const float* conv2_bias_dev, uint16_t* act_dev, const uint16_t* shared_view_selfcell_dev,
+                        int32_t device_id, void* stream);
 
 /* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
  *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)

@@ -116,7 +116,7 @@ SYMBOLS = {
     "ctf_reset": (C.c_int, [_P, _P, _P]),
     "ctf_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_observe": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
-    "ctf_observe_codes": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
+    "ctf_observe_codes": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_step_observe": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P]),
     "ctf_action_mask": (C.c_int, [_P, _P]),
     "ctf_get_state": (C.c_int, [_P, C.c_int32, C.POINTER(CtfStateView)]),
@@ -131,7 +131,7 @@ SYMBOLS = {
     # include/ctf_policy.h
     "ctf_policy_act_stride": (C.c_int32, [C.c_int32, C.c_int32]),
     "ctf_policy_features": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
-                                      _P, _P, _P, _P, _P, C.c_int32, _P]),
+                                      _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "ctf_policy_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P,
                                   C.c_int32, _P]),
     "ctf_policy_last_error": (C.c_char_p, []),

@@ -18,7 +18,7 @@ extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint6
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
 extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
-extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
+extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
 
@@ -359,12 +359,11 @@ extern "C" int ctf_observe(ctf_env* h, uint8_t* obs, uint16_t* meta, uint32_t re
     return CTF_OK;
 }
 
-extern "C" int ctf_observe_codes(ctf_env* h, uint8_t* codes, uint16_t* meta, uint32_t reverse_mask, void* stream) {
+extern "C" int ctf_observe_codes(ctf_env* h, uint8_t* codes, uint16_t* meta, uint16_t* selfcells, uint32_t reverse_mask, void* stream) {
     if (!h) return fail(CTF_E_INVALID, "null handle");
-    if (!codes && !meta) return CTF_OK;
+    if (!codes && !meta && !selfcells) return CTF_OK;
     DeviceGuard guard(h->device);
-    const uint32_t rev = resolve_reverse(h, reverse_mask);
-    HIP_TRY(ctf_launch_observe_codes(h->d, h->p, codes, meta, rev, h->n_cus, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_observe_codes(h->d, h->p, codes, meta, selfcells, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;
 }
 

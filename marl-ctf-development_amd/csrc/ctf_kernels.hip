@@ -1096,7 +1096,8 @@ __host__ __device__ inline int codes_wave_bytes(int GS, int RS, int GG, int N, i
 
 template <bool DWORDS>
 __global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ codes,
-                                                       uint16_t* __restrict__ meta, uint32_t reverse_mask) {
+                                                       uint16_t* __restrict__ meta, uint16_t* __restrict__ selfcells,
+                                                       uint32_t reverse_mask) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
@@ -1133,12 +1134,15 @@ __global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, ui
         for (int w = lane + WAVE; w < GW; w += WAVE) ((uint32_t*)sgrid)[w] = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16
         // parks the record in LDS and, when asked for, writes this env's metadata rows
         obs_build_env(cfg, p, e, recw, 0u, srec, mv, mstage, mlut, nullptr, slots, reverse_mask, lane, false, meta);
-        if (!codes) continue;
+        if (!codes && !selfcells) continue;
         if (lane < N) {
             const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
             const int r = ps[2 * lane], c = ps[2 * lane + 1];
-            selfc[lane] = (uint16_t)(((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c);
+            const uint16_t sc = (uint16_t)(((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c);
+            selfc[lane] = sc;
+            if (selfcells) selfcells[(size_t)e * N + lane] = sc;  // where bit 7 sits in this agent's row
         }
+        if (!codes) continue;
 #pragma unroll
         for (int slot = 0; slot < 4; slot++) {
             if (!slots.a[slot]) continue;  // uniform
@@ -1293,8 +1297,8 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     return hipGetLastError();
 }
-extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint16_t* meta, uint32_t reverse_mask,
-                                               int n_cus, hipStream_t st) {
+extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint16_t* meta, uint16_t* selfcells,
+                                               uint32_t reverse_mask, int n_cus, hipStream_t st) {
     const int per_wave = codes_wave_bytes(cfg.GS, cfg.RS, cfg.GG, cfg.N, cfg.M);
     int wpb = 4;
     while (wpb > 1 && wpb * per_wave > 40 * 1024) wpb >>= 1;
@@ -1302,8 +1306,8 @@ extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs&
     int blocks = (cfg.n_envs + wpb - 1) / wpb;
     if (blocks > n_cus * 8) blocks = n_cus * 8;
     const bool dwords = ((cfg.N * cfg.GG) % 4) == 0 && ((uintptr_t)codes % 4) == 0;
-    if (dwords) hipLaunchKernelGGL(k_observe_codes<true>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, meta, reverse_mask);
-    else hipLaunchKernelGGL(k_observe_codes<false>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, meta, reverse_mask);
+    if (dwords) hipLaunchKernelGGL(k_observe_codes<true>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, meta, selfcells, reverse_mask);
+    else hipLaunchKernelGGL(k_observe_codes<false>, dim3(blocks), dim3(wpb * WAVE), sh, st, cfg, p, codes, meta, selfcells, reverse_mask);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg& cfg, const DevPtrs& p, int32_t* metrics, int32_t* captures, int32_t* steps,

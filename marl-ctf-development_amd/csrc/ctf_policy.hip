@@ -10,9 +10,10 @@
 //   h1  LDS bf16 [2 halves][G1*G1 positions][8 ch]  tanh(conv1), written 8 bytes per lane from the accumulator layout
 //   conv2 = 32x32x16 MFMAs: D[out ch][position], one MFMA per tap (K = 16 in ch), B = ds_read_b128 of h1 rows
 //   out HBM bf16 [sample][Kp]            tanh(conv2) as 8-byte stores in the order the accumulators hold it:
-//           column ((c/4) * P2 + p) * 4 + c%4 for out channel c, position p — the fc1 weight's columns are permuted to this
-//           order once on the host (policy_native.py), so no transpose happens anywhere; then the M metadata values
-//           (f16 -> bf16) and zero padding up to Kp (a multiple of 32).
+//           column ((c/4) * PP + p) * 4 + c%4 for out channel c, position p (PP = positions rounded up to whole
+//           32-position tiles, so that every store instruction covers whole 128-byte lines) — the fc1 weight's columns
+//           are permuted to this order once on the host (policy_native.py), so no transpose happens anywhere; then the M
+//           metadata values (f16 -> bf16) and padding up to Kp (a multiple of 64: rows are whole lines).
 // tanh(x) = 1 - 2 / (2^(x * 2 log2 e) + 1): the factor 2 log2 e is folded into the conv weights and biases on the host,
 // so an activation costs v_exp_f32 + v_add + v_rcp_f32 + v_fma.
 // fc1 / fc2 / heads are plain GEMMs and stay with hipBLASLt (through torch).
@@ -25,7 +26,8 @@
 #define WAVE 64
 // Profiling-only ablations (never defined in the shipped build; tools/ablate_policy.sh):
 //   bit0 no activation stores, bit1 no exp/rcp in tanh, bit2 no h0 update, bit3 every operand read from one LDS address,
-//   bit4 every sample of a wave stored to the same row (store instructions without the HBM traffic)
+//   bit4 every sample of a wave stored to the same row (store instructions without the HBM traffic),
+//   bit5 team kernel: half of the shared activation stores skipped
 #ifndef POL_ABLATE
 #define POL_ABLATE 0
 #endif
@@ -85,11 +87,43 @@ __device__ __forceinline__ PolCodes<NP> pol_load_codes(const uint8_t* cp, int la
     return v;
 }
 
+// Loads the compiler does not track (the idiom of k_observe): left to itself it sinks a "prefetch" down to its first use, i.e.
+// BEHIND the sample's stores, and then waits with vmcnt(0) — which also drains every one of those stores before the next
+// sample may start.  Issued by hand at the top of a sample and waited for with a COUNTED vmcnt (the counter retires in
+// issue order; the stores issued since are younger), the next sample's inputs arrive while this one computes and the
+// stores keep draining in the background.
+__device__ __forceinline__ uint32_t pol_async_ubyte(const uint8_t* ptr) {
+    uint32_t v;
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t pol_async_ushort(const uint16_t* ptr) {
+    uint32_t v;
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t pol_async_dword(const uint32_t* ptr) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+template <int NP>
+__device__ __forceinline__ PolCodes<NP> pol_async_codes(const uint8_t* cp, int lane, int GG) {
+    PolCodes<NP> v;
+#pragma unroll
+    for (int q = 0; q < NP; q++) v.b[q] = pol_async_ubyte(cp + min(lane + WAVE * q, GG - 1));  // clamped, not predicated: every lane loads
+    return v;
+}
+// wait until at most N vector-memory operations are outstanding; ties the prefetched registers to the wait
+#define POL_WAIT_VM(N, r0, r1, r2, r3, r4) \
+    asm volatile("s_waitcnt vmcnt(%c5)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "n"(N) : "memory")
+
 template <int TG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_policy_features(PolicyArgs a) {
     extern __shared__ uint32_t lds[];
     const int G = TG ? TG : a.G;
     const int G1 = G - 2, G2 = G - 4, GG = G * G, P1 = G1 * G1, P2 = G2 * G2;
+    const int PP = ((P2 + 31) >> 5) << 5;  // positions per channel group in the activation row: whole 32-position tiles
     // FAST (G*G <= 256, a compile-time G): h0 persists across the wave's samples and only the cells whose code changed
     // are rewritten; the next sample's codes and metadata are loaded one sample ahead.
     constexpr bool FAST = TG != 0 && TG * TG <= 256;
@@ -132,7 +166,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
     const int S = a.n_sel * a.n_envs;
     const int s_first = blockIdx.x * wpb + wave, s_stride = gridDim.x * wpb;
-    const int npair = (a.Kp - 32 * P2) >> 1;
+    const int npair = (a.Kp - 32 * PP) >> 1;
 
     PolCodes<NP> oldc, nextc;
 #pragma unroll
@@ -153,14 +187,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         uint16_t* arow = a.act + (size_t)((POL_ABLATE & 16) ? s_first : s) * a.Kp;
         uint32_t two = 0;
         if (FAST) {
+            // the loads below are older than the 1 + 4 T2 stores of the previous sample: a counted wait leaves those in flight
+            constexpr int STORES = 1 + 4 * ((((TG - 4) * (TG - 4)) + 31) >> 5);
+            static_assert(NP <= 4, "POL_WAIT_VM ties four code registers");
+            if (POL_ABLATE == 0) POL_WAIT_VM(STORES, nextc.b[0], nextc.b[NP > 1 ? 1 : 0], nextc.b[NP > 2 ? 2 : 0], nextc.b[NP > 3 ? 3 : 0], nextm);
             const PolCodes<NP> cur = nextc;
             two = nextm;
-            const int sn = s + s_stride;
-            if (sn < S) {  // next sample's inputs: in flight while this one computes
+            {   // next sample's inputs (the last sample re-reads itself: every lane always issues the same loads)
+                const int sn = min(s + s_stride, S - 1);
                 const int k = sn / a.n_envs, e = sn - k * a.n_envs;
                 const size_t row = (size_t)e * a.N + (int)((a.sel_pack >> (4 * k)) & 15u);
-                nextc = pol_load_codes<NP>(a.codes + row * GG, lane, GG);
-                if (lane < (a.M >> 1)) nextm = ((const uint32_t*)(a.meta + row * a.M))[lane];
+                if (POL_ABLATE == 0) {
+                    nextc = pol_async_codes<NP>(a.codes + row * GG, lane, GG);
+                    nextm = pol_async_dword((const uint32_t*)(a.meta + row * a.M) + min(lane, (a.M >> 1) - 1));
+                } else {
+                    nextc = pol_load_codes<NP>(a.codes + row * GG, lane, GG);
+                    nextm = ((const uint32_t*)(a.meta + row * a.M))[min(lane, (a.M >> 1) - 1)];
+                }
             }
             // h0 rows are one-hot: clear the previous sample's halfword, set this one's; slot 0 (own position) last
 #pragma unroll
@@ -200,7 +243,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 const float hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(two >> 16));
                 out = pack_bf16(lo, hi);
             }
-            ((uint32_t*)(arow + 32 * P2))[lane] = out;
+            ((uint32_t*)(arow + 32 * PP))[lane] = out;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
@@ -272,25 +315,293 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(bb), acc_b, 0, 0, 0);
             }
             // one address per pass: the four channel groups of a lane sit (2 q - 3) * P2 * 4 elements around `mid`
-            uint16_t* mid = arow + ((3 + hh) * P2 + pa) * 4;
-            if ((POL_ABLATE & 1) ? (acc_a[0] == 12345.0f && acc_b[5] == 1.0f) : (pa < P2)) {
+            uint16_t* mid = arow + ((3 + hh) * PP + pa) * 4;
+            // every lane stores, also the positions past P2 of the last tile (finite values under zero fc1 weights): whole lines
+            if ((POL_ABLATE & 1) ? (acc_a[0] == 12345.0f && acc_b[5] == 1.0f) : true) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     u32x2_t o;
                     o[0] = tanh2_pack(acc_a[4 * q], acc_a[4 * q + 1]);
                     o[1] = tanh2_pack(acc_a[4 * q + 2], acc_a[4 * q + 3]);
-                    *(u32x2_t*)(mid + (2 * q - 3) * P2 * 4) = o;
+                    *(u32x2_t*)(mid + (2 * q - 3) * PP * 4) = o;
                 }
             }
-            if ((POL_ABLATE & 1) ? (acc_b[0] == 12345.0f && acc_a[7] == 1.0f) : (pb < P2)) {
+            if ((POL_ABLATE & 1) ? (acc_b[0] == 12345.0f && acc_a[7] == 1.0f) : (pb < PP)) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     u32x2_t o;
                     o[0] = tanh2_pack(acc_b[4 * q], acc_b[4 * q + 1]);
                     o[1] = tanh2_pack(acc_b[4 * q + 2], acc_b[4 * q + 3]);
-                    *(u32x2_t*)(mid + (2 * q - 3) * P2 * 4 + 32 * 4) = o;
+                    *(u32x2_t*)(mid + (2 * q - 3) * PP * 4 + 32 * 4) = o;
                 }
             }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the same front for agents that SHARE A VIEW
+// ------------------------------------------------------------------------------------------------
+// Teammates looking through the same reversal see identical tile planes (the relabelling is by team,
+// gridworld_ctf.py:981-988); only plane 0, the own-position bit, differs.  One such bit reaches 3 x 3 conv1 outputs and
+// 5 x 5 conv2 outputs, so a wave takes one env and ALL `A` selected agents of the group:
+//   shared   conv1 -> tanh -> h1, conv2 -> tanh once, without any own-position bit; every agent's activation row gets the
+//            shared values outside its 5 x 5 patch;
+//   per agent  the own-position bit is switched on in h0, ONE 16-position tile recomputes the 3 x 3 conv1 patch into h1
+//            (the shared values it displaces are kept in registers), ONE 32-position tile recomputes the 5 x 5 conv2 patch and
+//            stores it; h1 and h0 are restored.  A lane's operand address is arbitrary, so a patch is just another tile.
+// Per agent that is 14 MFMAs and 40 transcendental instructions instead of 96 and 216.  The arithmetic of every output
+// is the same sum in the same order as in k_policy_features, so the two kernels agree bit for bit.
+// Profiling-only phase trace of the team kernel (tools/trace_team.py builds with -DPOL_TRACE=1): wave 0 of block 0 records
+// s_memtime at the phase boundaries of its first envs.
+#ifndef POL_TRACE
+#define POL_TRACE 0
+#endif
+#if POL_TRACE
+__device__ uint64_t g_pol_trace[16 * 64];
+extern "C" int ctf_policy_trace_read(uint64_t* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pol_trace), sizeof(uint64_t) * 16 * 64) == hipSuccess ? 0 : -1;
+}
+#define POL_STAMP(slot)                                                                         \
+    do {                                                                                        \
+        if (blockIdx.x == 0 && wave == 0 && trace_env < 64) {                                   \
+            const uint64_t tstamp = __builtin_amdgcn_s_memtime();                               \
+            if (lane == 0) g_pol_trace[trace_env * 16 + (slot)] = tstamp;                       \
+        }                                                                                       \
+    } while (0)
+#else
+#define POL_STAMP(slot) do { } while (0)
+#endif
+
+struct TeamArgs {
+    PolicyArgs p;
+    const uint16_t* selfcells;  // u16 [E][N]: the cell of every agent's own-position bit (ctf_observe_codes)
+    int32_t A;                  // agents in the group (<= 4): p.sel_pack nibbles 0..A-1, all sharing planes 1..C-1
+};
+
+template <int TG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_policy_features_team(TeamArgs ta) {
+    extern __shared__ uint32_t lds[];
+    const PolicyArgs& a = ta.p;
+    constexpr int G = TG, G1 = G - 2, G2 = G - 4, GG = G * G, P1 = G1 * G1, P2 = G2 * G2, PP = ((P2 + 31) >> 5) << 5;
+    constexpr int NP = (GG + WAVE - 1) / WAVE;
+    static_assert(GG <= 256, "one dword of code bytes per lane");
+    const int A = ta.A;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int wpb = blockDim.x / WAVE;
+    uint8_t* h0 = (uint8_t*)lds + wave * (pol_h0_bytes(G) + pol_h1_bytes(G));
+    uint8_t* h1 = h0 + pol_h0_bytes(G);
+    constexpr int H0A = GG * 16;
+    const int H1A = pol_h1_bytes(G) / 2;
+
+    u32x4_t w1[5], w2[9];
+#pragma unroll
+    for (int s = 0; s < 5; s++) w1[s] = a.w1frag[s * WAVE + lane];
+#pragma unroll
+    for (int t = 0; t < 9; t++) w2[t] = a.w2frag[t * WAVE + lane];
+    f32x4_t bias1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias1[r] = a.b1[(lane >> 4) * 4 + r];
+    f32x16_t bias2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) bias2[r] = a.b2[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+
+    const int n1 = lane & 15, g1 = lane >> 4;
+    int off1[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int tap = min(2 * s + (g1 >> 1), 8);
+        off1[s] = ((tap / 3) * G + (tap % 3)) * 16 + (g1 & 1) * H0A;
+    }
+    const int y1_0 = (int)(((uint32_t)n1 * a.inv_g1) >> 16), x1_0 = n1 - y1_0 * G1;
+    constexpr int dy1 = 16 / G1, dx1 = 16 - dy1 * G1;
+    uint8_t* h1w = h1 + (g1 >> 1) * H1A + n1 * 16 + (g1 & 1) * 8;
+    const int n2 = lane & 31, hh = lane >> 5;
+    // patch tiles: conv1 lane n -> offset (n / 3, n % 3) of the 3 x 3 patch (n < 9), conv2 lane n -> (n / 5, n % 5) (n < 25)
+    const int j1 = min(n1, 8), pdy1 = j1 / 3, pdx1 = j1 - 3 * pdy1;
+    const int j2 = min(n2, 24), pdy2 = j2 / 5, pdx2 = j2 - 5 * pdy2;
+    const int h1w_half = (g1 >> 1) * H1A + (g1 & 1) * 8;
+
+    const int npair = (a.Kp - 32 * PP) >> 1;
+    const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
+    const int ag0 = (int)(a.sel_pack & 15u);
+    const size_t agent_stride = (size_t)a.n_envs * a.Kp * 2;  // bytes from agent k's rows to agent k + 1's
+
+    PolCodes<NP> oldc, nextc;
+#pragma unroll
+    for (int q = 0; q < NP; q++) oldc.b[q] = nextc.b[q] = 0;
+    {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        for (int q = lane; q < GG * 2; q += WAVE) ((u32x4_t*)h0)[q] = z;
+        if (e_first < a.n_envs) nextc = pol_load_codes<NP>(a.codes + ((size_t)e_first * a.N + ag0) * GG, lane, GG);
+    }
+
+    int trace_env = 0;
+    (void)trace_env;
+    for (int e = e_first; e < a.n_envs; e += e_stride, trace_env++) {
+        POL_STAMP(0);
+        // nextc was issued at the top of the previous env and is older than that env's drain (below): it has arrived
+        const PolCodes<NP> cur = nextc;
+        nextc = pol_async_codes<NP>(a.codes + ((size_t)min(e + e_stride, a.n_envs - 1) * a.N + ag0) * GG, lane, GG);
+        // every agent's own cell and metadata: needed only after the shared pass (waited for by the drain there)
+        uint32_t scw[4], metaw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t row = (size_t)e * a.N + (int)((a.sel_pack >> (4 * min(k, A - 1))) & 15u);  // k >= A: agent A - 1 again
+            scw[k] = pol_async_ushort(ta.selfcells + row);
+            metaw[k] = pol_async_dword((const uint32_t*)(a.meta + row * a.M) + min(lane, (a.M >> 1) - 1));
+        }
+        // ---- h0 <- the shared planes (own-position bits stripped)
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const int c = lane + WAVE * q;
+            const uint32_t o = oldc.b[q] & 0x7Fu, n = cur.b[q] & 0x7Fu;
+            if (c < GG && o != n) {
+                uint8_t* cellp = h0 + c * 16;
+                *(uint16_t*)(cellp + (o >> 3) * H0A + (o & 7u) * 2) = 0;
+                if (n) *(uint16_t*)(cellp + (n >> 3) * H0A + (n & 7u) * 2) = 0x3F80;
+            }
+        }
+        oldc = cur;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        POL_STAMP(1);
+
+        // ---- shared conv1 + tanh -> h1   (one tile at a time: registers are the scarce resource here, and with three waves per
+        // SIMD a second accumulator chain per wave bought nothing in k_policy_features)
+        constexpr int T1 = (P1 + 15) >> 4;
+        int x1 = x1_0, cell1 = y1_0 * G + x1_0;
+#pragma unroll 1
+        for (int t = 0; t < T1; t++) {
+            const uint8_t* base = h0 + cell1 * 16;
+            x1 += dx1;
+            cell1 += dy1 * G + dx1;
+            if (x1 >= G1) { x1 -= G1; cell1 += G - G1; }
+            f32x4_t acc = bias1;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const u32x4_t b = *(const u32x4_t*)(base + off1[q]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w1[q]), as_bf16x8(b), acc, 0, 0, 0);
+            }
+            u32x2_t o;
+            o[0] = tanh2_pack(acc[0], acc[1]);
+            o[1] = tanh2_pack(acc[2], acc[3]);
+            *(u32x2_t*)(h1w + 16 * t * 16) = o;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        POL_STAMP(2);
+
+        // ---- shared conv2 + tanh -> EVERY agent's row, all positions; the agent's 5 x 5 patch is overwritten below
+        uint8_t* const act_env = (uint8_t*)a.act + (size_t)e * a.Kp * 2;  // agent 0's row of this env (uniform)
+        constexpr int T2 = (P2 + 31) >> 5;
+#pragma unroll 1
+        for (int t2 = 0; t2 < T2; t2++) {
+            const int p = 32 * t2 + n2, pc = min(p, P2 - 1);
+            const int y = (int)(((uint32_t)pc * a.inv_g2) >> 16), x = pc - y * G2;
+            const uint8_t* base = h1 + (y * G1 + x) * 16 + hh * H1A;
+            f32x16_t acc = bias2;
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const u32x4_t b = *(const u32x4_t*)(base + ((tap / 3) * G1 + (tap % 3)) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(b), acc, 0, 0, 0);
+            }
+            {   // every lane stores (also the positions past P2 of the last tile: finite values under zero fc1 weights): whole lines
+                const uint32_t lane_off = (uint32_t)(((3 + hh) * PP + p) * 8);  // the four channel groups sit (2 q - 3) * PP * 8 around it
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u32x2_t o;
+                    o[0] = tanh2_pack(acc[4 * q], acc[4 * q + 1]);
+                    o[1] = tanh2_pack(acc[4 * q + 2], acc[4 * q + 3]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (k < A && !((POL_ABLATE & 32) && (q & 1))) *(u32x2_t*)(act_env + k * agent_stride + lane_off + (2 * q - 3) * PP * 8) = o;
+                }
+            }
+        }
+        POL_STAMP(3);
+        // the patch stores below hit addresses written above: have those writes acknowledged first.  The same drain is the
+        // wait for this env's own cells / metadata and for the next env's codes, all issued before the stores.
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(scw[0]), "+v"(scw[1]), "+v"(scw[2]), "+v"(scw[3]), "+v"(metaw[0]), "+v"(metaw[1]), "+v"(metaw[2]),
+                       "+v"(metaw[3]), "+v"(nextc.b[0]), "+v"(nextc.b[NP > 1 ? 1 : 0]), "+v"(nextc.b[NP > 2 ? 2 : 0]),
+                       "+v"(nextc.b[NP > 3 ? 3 : 0])
+                     :
+                     : "memory");
+
+        POL_STAMP(4);
+        // ---- per agent: own-position bit on, the two patches, everything restored
+#pragma unroll 1
+        for (int k = 0; k < A; k++) {
+            // (select chains, not indexing: the arrays live in registers)
+            const int sc = __builtin_amdgcn_readfirstlane((int)(k == 0 ? scw[0] : k == 1 ? scw[1] : k == 2 ? scw[2] : scw[3]));
+            const uint32_t mw = k == 0 ? metaw[0] : k == 1 ? metaw[1] : k == 2 ? metaw[2] : metaw[3];
+            const int syk = sc / G, sxk = sc - syk * G;
+            uint8_t* const arow = act_env + k * agent_stride;
+            if (lane < npair) {  // metadata behind the conv features
+                uint32_t out = 0;
+                if (lane < (a.M >> 1)) {
+                    const float lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(mw & 0xFFFFu));
+                    const float hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(mw >> 16));
+                    out = pack_bf16(lo, hi);
+                }
+                ((uint32_t*)(arow + 32 * PP * 2))[lane] = out;
+            }
+            uint16_t* selfp = (uint16_t*)(h0 + sc * 16);  // channel 0 of the own cell
+            if (lane == 0) *selfp = 0x3F80;
+            // conv1 patch: outputs (sy - 2 + dy, sx - 2 + dx), dy, dx in 0..2
+            const int oy1 = syk - 2 + pdy1, ox1 = sxk - 2 + pdx1;
+            const bool ok1 = n1 < 9 && (unsigned)oy1 < (unsigned)G1 && (unsigned)ox1 < (unsigned)G1;
+            const int cy1 = min(max(oy1, 0), G1 - 1), cx1 = min(max(ox1, 0), G1 - 1);
+            u32x2_t* h1p = (u32x2_t*)(h1 + h1w_half + (cy1 * G1 + cx1) * 16);
+            const u32x2_t keep = *h1p;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            {
+                const uint8_t* base = h0 + (cy1 * G + cx1) * 16;
+                f32x4_t acc = bias1;
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const u32x4_t b = *(const u32x4_t*)(base + off1[q]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w1[q]), as_bf16x8(b), acc, 0, 0, 0);
+                }
+                u32x2_t o;
+                o[0] = tanh2_pack(acc[0], acc[1]);
+                o[1] = tanh2_pack(acc[2], acc[3]);
+                if (ok1) *h1p = o;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            // conv2 patch: outputs (sy - 4 + dy, sx - 4 + dx), dy, dx in 0..4
+            {
+                const int oy2 = syk - 4 + pdy2, ox2 = sxk - 4 + pdx2;
+                const bool ok2 = n2 < 25 && (unsigned)oy2 < (unsigned)G2 && (unsigned)ox2 < (unsigned)G2;
+                const int cy2 = min(max(oy2, 0), G2 - 1), cx2 = min(max(ox2, 0), G2 - 1);
+                const uint8_t* base = h1 + (cy2 * G1 + cx2) * 16 + hh * H1A;
+                f32x16_t acc = bias2;
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    const u32x4_t b = *(const u32x4_t*)(base + ((tap / 3) * G1 + (tap % 3)) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(b), acc, 0, 0, 0);
+                }
+                if (ok2) {
+                    const uint32_t lane_off = (uint32_t)(((3 + hh) * PP + oy2 * G2 + ox2) * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        u32x2_t o;
+                        o[0] = tanh2_pack(acc[4 * q], acc[4 * q + 1]);
+                        o[1] = tanh2_pack(acc[4 * q + 2], acc[4 * q + 3]);
+                        *(u32x2_t*)(arow + lane_off + (2 * q - 3) * PP * 8) = o;
+                    }
+                }
+            }
+            // restore the shared image (the reads above are done: LDS serves a wave's operations in order)
+            if (ok1) *h1p = keep;
+            if (lane == 0) *selfp = 0;
+            POL_STAMP(5 + k);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
@@ -500,14 +811,15 @@ static int policy_n_cus(int device_id) {
 }
 
 extern "C" int32_t ctf_policy_act_stride(int32_t grid_size, int32_t meta_len) {
-    const int p2 = (grid_size - 4) * (grid_size - 4);
-    return (32 * p2 + meta_len + 31) & ~31;
+    const int pp = (((grid_size - 4) * (grid_size - 4) + 31) >> 5) << 5;  // positions padded to whole 32-position tiles
+    return (32 * pp + meta_len + 63) & ~63;                               // rows are whole 128-byte lines
 }
 
 extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* meta_dev, int32_t n_envs, int32_t n_agents,
                                    int32_t grid_size, int32_t meta_len, const int32_t* agent_sel, int32_t n_sel,
                                    const void* conv1_frag_dev, const float* conv1_bias_dev, const void* conv2_frag_dev,
-                                   const float* conv2_bias_dev, uint16_t* act_dev, int32_t device_id, void* stream) {
+                                   const float* conv2_bias_dev, uint16_t* act_dev, const uint16_t* shared_view_selfcell_dev,
+                                   int32_t device_id, void* stream) {
     if (!codes_dev || !meta_dev || !agent_sel || !conv1_frag_dev || !conv1_bias_dev || !conv2_frag_dev || !conv2_bias_dev || !act_dev)
         return pfail("null argument");
     if (grid_size < 5 || grid_size > 32) return pfail("grid_size outside 5..32");
@@ -551,7 +863,22 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
     if (blocks > n_cus * per_cu) blocks = n_cus * per_cu;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
-    if (grid_size == 15) {
+    if (shared_view_selfcell_dev && n_sel <= 4 && (grid_size == 15 || grid_size == 11)) {
+        // agents sharing a view: one wave per env does the shared work once and a small patch per agent
+        TeamArgs ta;
+        ta.p = a;
+        ta.selfcells = shared_view_selfcell_dev;
+        ta.A = n_sel;
+        int tblocks = (n_envs + wpb - 1) / wpb;
+        if (tblocks > n_cus * per_cu) tblocks = n_cus * per_cu;
+        if (grid_size == 15) {
+            if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_features_team<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            if (err == hipSuccess) hipLaunchKernelGGL(k_policy_features_team<15>, dim3(tblocks), dim3(wpb * WAVE), sh, st, ta);
+        } else {
+            if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_features_team<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            if (err == hipSuccess) hipLaunchKernelGGL(k_policy_features_team<11>, dim3(tblocks), dim3(wpb * WAVE), sh, st, ta);
+        }
+    } else if (grid_size == 15) {
         if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_features<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (err == hipSuccess) hipLaunchKernelGGL(k_policy_features<15>, dim3(blocks), dim3(wpb * WAVE), sh, st, a);
     } else if (grid_size == 11) {

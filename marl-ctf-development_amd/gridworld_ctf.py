@@ -94,6 +94,7 @@ class VecGridworldCtf:
         self.done = torch.zeros((E,), dtype=torch.uint8, device=self.device)
         self._obs = None  # uint8 [E, N, C, G, G]: allocated (and placed) on first use — a codes-only caller never pays for it
         self._codes = None
+        self._self_cells = None
         self.meta = torch.zeros((E, N, self.META_LEN), dtype=torch.float16, device=self.device)
         self.seed(py_seeds, np_seeds)
         if tune_placement is None:
@@ -220,11 +221,20 @@ class VecGridworldCtf:
 
     def observe_codes(self, reverse_mask=None, codes=True, meta=True):
         """The observation in compact form -> (codes uint8 [E, N, G, G], meta float16 [E, N, 2N+6]): low 7 bits = the tile
-        plane (1..C-1) that is 1 at the cell, 0 = none; bit 7 = plane 0 (own position).  ``expand_codes`` gives the planes."""
+        plane (1..C-1) that is 1 at the cell, 0 = none; bit 7 = plane 0 (own position).  ``expand_codes`` gives the planes.
+        ``self.self_cells`` (uint16 [E, N]) receives the cell index of every agent's bit 7 in the same launch."""
         rm = _abi.REVERSE_DEFAULT if reverse_mask is None else int(reverse_mask) & ((1 << self.N_AGENTS) - 1)
+        if self._self_cells is None:
+            self._self_cells = _torch().zeros((self.n_envs, self.N_AGENTS), dtype=_torch().int16, device=self.device)
         _abi.check(self._lib.ctf_observe_codes(self._h, C.c_void_p(self.codes.data_ptr()) if codes else None,
-                                               C.c_void_p(self.meta.data_ptr()) if meta else None, rm, self._stream()), self._lib)
+                                               C.c_void_p(self.meta.data_ptr()) if meta else None,
+                                               C.c_void_p(self._self_cells.data_ptr()) if codes else None, rm, self._stream()), self._lib)
         return self.codes, self.meta
+
+    @property
+    def self_cells(self):
+        """int16 [E, N]: where bit 7 sits in each agent's row of the last ``observe_codes`` (None before the first)."""
+        return self._self_cells
 
     def step_observe(self, actions, auto_reset=False, want_f64=False, reverse_mask=None):
         """step() then observe() in one call -> (rewards, done, obs, meta)."""

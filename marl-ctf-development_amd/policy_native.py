@@ -57,14 +57,16 @@ def conv_fragments(conv1_w, conv1_b, conv2_w, conv2_b):
 
 
 def act_column_order(grid_size, meta_len):
-    """new column -> reference column of fc1's input (-1 = zero padding): the kernel writes conv2 channel c, position p at
-    ((c // 4) * P2 + p) * 4 + c % 4, the reference's flatten at c * P2 + p; metadata follows in both."""
+    """new column -> reference column of fc1's input (-1 = padding, zero weight): the kernel writes conv2 channel c,
+    position p at ((c // 4) * PP + p) * 4 + c % 4 with PP = the positions rounded up to whole 32-position tiles (every
+    store instruction then covers whole 128-byte lines); the reference's flatten has it at c * P2 + p; metadata follows."""
     p2 = (grid_size - 4) ** 2
-    kp = (32 * p2 + meta_len + 31) // 32 * 32
+    pp = (p2 + 31) // 32 * 32
+    kp = (32 * pp + meta_len + 63) // 64 * 64
     src = np.full(kp, -1, np.int64)
     c, p = np.meshgrid(np.arange(32), np.arange(p2), indexing="ij")
-    src[((c // 4) * p2 + p) * 4 + c % 4] = c * p2 + p
-    src[32 * p2:32 * p2 + meta_len] = 32 * p2 + np.arange(meta_len)
+    src[((c // 4) * pp + p) * 4 + c % 4] = c * p2 + p
+    src[32 * pp:32 * pp + meta_len] = 32 * p2 + np.arange(meta_len)
     return src
 
 
@@ -139,9 +141,12 @@ class CtfPolicyNative(CtfPolicy):
         return self._prep
 
     # -- inference from the compact observation ----------------------------------------------------
-    def features_from_codes(self, codes, meta, agent_idx, out=None):
+    def features_from_codes(self, codes, meta, agent_idx, out=None, shared_view=False, self_cells=None):
         """codes uint8 [E, N, G, G], meta float16 [E, N, M], agent_idx: the agents this network plays ->
-        bf16 [len(agent_idx) * E, Kp] (row k * E + e = agent agent_idx[k] of env e)."""
+        bf16 [len(agent_idx) * E, Kp] (row k * E + e = agent agent_idx[k] of env e).  ``shared_view``: the caller's promise
+        that these agents see the same tile planes (same team, same reverse flag): the convolutions then run once per env
+        plus a small patch per agent, with bit-identical results.  ``self_cells``: int16 [E, N] of ``vec.self_cells`` (where
+        each row's bit 7 sits); derived from ``codes`` when not given."""
         p = self._ready()
         E, N = int(codes.shape[0]), int(codes.shape[1])
         if not (codes.is_cuda and codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape[2:]) == (self.grid_size,) * 2):
@@ -154,10 +159,17 @@ class CtfPolicyNative(CtfPolicy):
         elif not (out.dtype == torch.bfloat16 and out.is_contiguous() and tuple(out.shape) == (len(sel) * E, p["kp"])):
             raise ValueError("out must be a contiguous bfloat16 tensor [len(agent_idx) * E, Kp]")
         sel_arr = (C.c_int32 * len(sel))(*sel)
+        sc_ptr = None
+        if shared_view and len(sel) <= 4:
+            if self_cells is None:
+                self_cells = (codes >> 7).flatten(2).argmax(dim=2).to(torch.int16)
+            if not (self_cells.is_cuda and self_cells.dtype == torch.int16 and self_cells.is_contiguous() and tuple(self_cells.shape) == (E, N)):
+                raise ValueError("self_cells must be a contiguous int16 CUDA tensor [E, N]")
+            sc_ptr = C.c_void_p(self_cells.data_ptr())
         rc = p["lib"].ctf_policy_features(
             C.c_void_p(codes.data_ptr()), C.c_void_p(meta.data_ptr()), E, N, self.grid_size, self.metadata_size, sel_arr, len(sel),
             C.c_void_p(p["f1"].data_ptr()), C.c_void_p(p["b1"].data_ptr()), C.c_void_p(p["f2"].data_ptr()),
-            C.c_void_p(p["b2"].data_ptr()), C.c_void_p(out.data_ptr()), codes.device.index,
+            C.c_void_p(p["b2"].data_ptr()), C.c_void_p(out.data_ptr()), sc_ptr, codes.device.index,
             C.c_void_p(torch.cuda.current_stream(codes.device).cuda_stream))
         if rc != 0:
             raise _abi.CtfLibraryError("ctf_policy_features: " + (p["lib"].ctf_policy_last_error() or b"").decode())
@@ -199,10 +211,10 @@ class CtfPolicyNative(CtfPolicy):
                          given=torch.zeros(len(agent_idx) * codes.shape[0], dtype=torch.int32, device=codes.device))
         return out[3].reshape(-1, 1), out[4]
 
-    def act_from_codes(self, codes, meta, agent_idx, masking_decision_tensor, action=None):
+    def act_from_codes(self, codes, meta, agent_idx, masking_decision_tensor, action=None, shared_view=False, self_cells=None):
         """get_action_and_value (agent_network.py:63-81) for agents ``agent_idx`` of every env, from the compact observation:
         -> (action int32 [B], log_prob [B], entropy [B], value [B, 1]).  Sampling: inverse CDF of the masked softmax with one
         Philox4x32-10 uniform per sample, keyed by this module's seed and call count."""
-        act, logprob, entropy, value, _ = self._tail(self.features_from_codes(codes, meta, agent_idx), mask=masking_decision_tensor,
-                                                     given=action)
+        feats = self.features_from_codes(codes, meta, agent_idx, shared_view=shared_view, self_cells=self_cells)
+        act, logprob, entropy, value, _ = self._tail(feats, mask=masking_decision_tensor, given=action)
         return act, logprob, entropy, value.reshape(-1, 1)

@@ -91,7 +91,9 @@ class BatchedRolloutCollector:
         host list: no device round trip per step.)"""
         E, k = self.vec.n_envs, len(agents)
         mask = self.mask_flag.index_select(0, idx)[:, None].expand(-1, E).reshape(-1)
-        action, logprob, _, value = net.act_from_codes(codes, meta, agents, mask)
+        # one team, default reversal (by team): its agents look at the same tile planes
+        shared = len({self.vec.AGENT_TEAMS[i] for i in agents}) == 1
+        action, logprob, _, value = net.act_from_codes(codes, meta, agents, mask, shared_view=shared, self_cells=self.vec.self_cells)
         grid = md = None
         if want_inputs:  # views where the agents form a regular slice: the rollout buffer is then filled by ONE strided copy
             sl = self._as_slice(agents)

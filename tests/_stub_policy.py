@@ -44,7 +44,7 @@ class StubCodesPolicy(StubDuelPolicy):
         super().__init__(salt, n_actions)
         self.n_channels, self.expand_codes = int(n_channels), expand_codes
 
-    def act_from_codes(self, codes, meta, agent_idx, masking_decision_tensor, action=None):
+    def act_from_codes(self, codes, meta, agent_idx, masking_decision_tensor, action=None, shared_view=False, self_cells=None):
         idx = torch.tensor(list(agent_idx), device=codes.device)
         g = codes.shape[-1]
         planes = self.expand_codes(codes.index_select(1, idx).transpose(0, 1).reshape(-1, g, g), self.n_channels)

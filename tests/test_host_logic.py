@@ -109,11 +109,13 @@ def test_policy_kernel_operands_follow_the_documented_lane_maps():
     for g, m in ((15, 22), (11, 14), (7, 10)):
         order = native.act_column_order(g, m)
         p2 = (g - 4) ** 2
-        assert len(order) % 32 == 0 and len(order) >= 32 * p2 + m
+        pp = (p2 + 31) // 32 * 32
+        assert len(order) % 64 == 0 and len(order) >= 32 * pp + m         # rows are whole 128-byte lines
         real = order[order >= 0]
         assert sorted(real.tolist()) == list(range(32 * p2 + m))          # every reference column exactly once
         for c_, p_ in ((0, 0), (5, 3), (31, p2 - 1)):
-            assert order[((c_ // 4) * p2 + p_) * 4 + c_ % 4] == c_ * p2 + p_
+            assert order[((c_ // 4) * pp + p_) * 4 + c_ % 4] == c_ * p2 + p_
+        assert list(order[32 * pp:32 * pp + m]) == list(range(32 * p2, 32 * p2 + m))
 
     wf2, bf2 = rng.standard_normal((128, 256)), rng.standard_normal(128)
     wa, ba, wv, bv = rng.standard_normal((9, 128)), rng.standard_normal(9), rng.standard_normal((1, 128)), rng.standard_normal(1)

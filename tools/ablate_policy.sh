@@ -19,6 +19,6 @@ for v in $VARIANTS; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ablate_policy/v$v.json"))
-print("POL_ABLATE=$v features_ms", d["features"])
+print("POL_ABLATE=$v features_ms", d["features"], "two_teams_per_agent", d.get("features_two_teams_per_agent"), "shared_view", d.get("features_two_teams_shared_view"))
 PY
 done

@@ -47,6 +47,11 @@ def main():
         codes, meta = vec.observe_codes()
         feats = torch.zeros((B, p["kp"]), dtype=torch.bfloat16, device="cuda")
         out["features"] = timed(lambda: net.features_from_codes(codes, meta, sel, out=feats))
+        teams = [[i for i in range(vec.N_AGENTS) if vec.AGENT_TEAMS[i] == t] for t in (0, 1)]
+        halves = [feats[:len(teams[0]) * E], feats[len(teams[0]) * E:]]
+        out["features_two_teams_per_agent"] = timed(lambda: [net.features_from_codes(codes, meta, teams[t], out=halves[t]) for t in (0, 1)])
+        out["features_two_teams_shared_view"] = timed(
+            lambda: [net.features_from_codes(codes, meta, teams[t], out=halves[t], shared_view=True, self_cells=vec.self_cells) for t in (0, 1)])
         F = torch.nn.functional
         out["fc1"] = timed(lambda: F.linear(feats, p["fc1_w"], p["fc1_b"]))
         y1 = F.linear(feats, p["fc1_w"], p["fc1_b"])
