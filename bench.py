@@ -9,9 +9,9 @@ One "step" = one pass of the hot path over one batch: GridworldCtf.step() for ev
 plus the N observations + metadata rows a rollout consumes (reference ppo.py:59-98), with auto-reset at
 episode end.  Workload at N=1: BASELINE.json configs[2] — 8_arena (arena_iii, 4v4, the reference's
 15x15 map), 65 536 envs resident in HBM; N>1 keeps 65 536 envs per GPU (weak scaling), envs sharded by
-global index with no data-path collective, and the compact rollout tensors (rewards, done) all-gathered
-over RCCL each step, overlapped with the observation render.  Inputs (Philox action streams for every
-timed step) are generated on the device before the timed region.
+global index with no data-path collective (--rollout-exchange adds an asynchronous RCCL all-gather of the
+compact rollout tensors once per 16-step chunk, what a centralised learner would need).  Inputs (Philox
+action streams for every timed step) are generated on the device before the timed region.
 
 Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for the roofline / cpu_baseline fields).
 """
@@ -79,8 +79,17 @@ def main():
     ap.add_argument("--workload", choices=["arena", "split"], default="arena")
     ap.add_argument("--no-metrics", action="store_true", help="compile the reference's metric counters out of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout-exchange", action="store_true",
+                    help="also all-gather the compact rollout tensors (rewards, done) over RCCL, once per 16-step chunk, for a "
+                         "centralised learner; off by default: env shards are independent and a data-parallel learner needs no exchange")
     ap.add_argument("--run", type=int, default=1, help="seed family: env seeds are 1_000_003*run + global env index")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: native libraries (the RCCL banner at communicator init, for one) write to fd 1
+    # as well, so fd 1 is pointed at stderr for the run and the result goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -116,22 +125,26 @@ def main():
     actions = torch.empty((W + K, E, N), dtype=torch.int8, device=device)
     for t in range(W + K):
         vec.random_actions(actions[t], seed=0xC7F, step=t, env_offset=lo)
-    gather = sh.RolloutGather(vec.rewards, vec.done, world, force_collective=use_dist)
+    # The path shards with NO data-path collective: envs are independent, every rank steps and renders its own shard, and a
+    # data-parallel learner consumes the observations where they are.  --rollout-exchange adds the hand-off a centralised
+    # learner would need: the step kernel writes rewards / done straight into a chunk buffer that is all-gathered (RCCL,
+    # async) once per 16 steps.  Measured at one rank it costs 13 %: the collective's blocks take wave slots on a few CUs
+    # and the render, which fills every slot with equal shares of work, waits for its displaced blocks.
+    exchange = use_dist and args.rollout_exchange
+    gather = sh.ChunkedRolloutGather(E, N, device, world, chunk=16, force_collective=exchange)
     vec.observe()
 
     def one_step(t, events=None):
+        vec.rewards, vec.done = gather.views(t)
         if events:
             events[0].record()
-        rewards, done = vec.step(actions[t], auto_reset=True)
+        vec.step(actions[t], auto_reset=True)
         if events:
             events[1].record()
         vec.observe()
         if events:
             events[2].record()
-        # async RCCL all-gather of the compact rollout tensors (a copy at N=1).  Issued AFTER the render so that it runs
-        # beside the next step kernel (which leaves half of the wave slots free) — beside the render, which fills every
-        # slot with equal-sized shares of work, it delayed a few blocks and stretched the kernel by 15 %
-        gather.start(rewards, done)
+        gather.step_done(t)  # closes a chunk every 16th step: issued after the render, it runs beside the next step kernel
 
     for t in range(W):
         one_step(t)
@@ -143,6 +156,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(K):
         one_step(W + t, ev[t])
+    gather.flush(W + K)
     gather.wait()
     torch.cuda.synchronize()
     if use_dist:
@@ -191,7 +205,8 @@ def main():
                 "envs_per_gpu": E,
                 "global_envs": n_gpus * E,
                 "metrics_counters": not args.no_metrics,
-                "rollout_exchange": "RCCL all-gather of rewards+done per step, async" if use_dist else "none (1 GPU)",
+                "rollout_exchange": ("RCCL all-gather of rewards+done per 16-step chunk, async" if exchange else
+                                     "none: env shards are independent (data-parallel learner)"),
             },
             "roofline": {
                 "bound": "hbm",
@@ -214,7 +229,8 @@ def main():
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, kwargs)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     vec.close()
     if use_dist:
         dist.destroy_process_group()

@@ -1,8 +1,9 @@
 """Multi-GPU layout of the path: envs are independent, so each rank (one process per GPU) owns a
 contiguous range of global env indices with its own handle and stream, and stepping / rendering needs
 no communication.  The only exchange is the rollout hand-off to the learner: an all-gather of the
-compact per-step tensors (rewards, done) over RCCL (backend "nccl" on ROCm), issued asynchronously so
-it overlaps the observation render.  The same code runs over gloo on CPU tensors in the tests.
+compact per-step tensors (rewards, done) over RCCL (backend "nccl" on ROCm), issued asynchronously once
+per chunk of steps (ChunkedRolloutGather; RolloutGather is the per-step variant).  The same code runs
+over gloo on CPU tensors in the tests.
 """
 import os
 
@@ -78,6 +79,71 @@ class RolloutGather:
     def result(self, slot):
         self.wait(slot)
         return self.bufs[slot]
+
+
+class ChunkedRolloutGather:
+    """The same hand-off once per CHUNK of steps: the env writes step t's rewards / done straight into slot t % C of a
+    chunk buffer (``views``; no copy), and every C steps the whole chunk ([C, E, N] f32 + [C, E] u8) is all-gathered
+    asynchronously while the next chunk fills the other buffer.  A learner needs the rollout only when it is complete, so
+    nothing waits for the per-step latency of a collective, and its launch cost is paid once per C steps."""
+
+    def __init__(self, n_envs, n_agents, device, world, chunk=16, group=None, force_collective=False, dtype=None):
+        import torch
+
+        self.world, self.group, self.C = int(world), group, int(chunk)
+        self.collective = world > 1 or force_collective
+        f32 = dtype or torch.float32
+        self.local = [(torch.zeros((self.C, n_envs, n_agents), dtype=f32, device=device),
+                       torch.zeros((self.C, n_envs), dtype=torch.uint8, device=device)) for _ in range(2)]
+        self.glob = [(torch.zeros((self.world, self.C, n_envs, n_agents), dtype=f32, device=device),
+                      torch.zeros((self.world, self.C, n_envs), dtype=torch.uint8, device=device)) if self.collective else None
+                     for _ in range(2)]
+        self.pending = [None, None]
+
+    def views(self, t):
+        """-> (rewards [E, N], done [E]) that step t must write (e.g. ``vec.rewards, vec.done = gather.views(t)``)."""
+        b, i = (t // self.C) & 1, t % self.C
+        if i == 0:
+            self.wait(b)  # the gather that last read this buffer (two chunks ago) must be done before it is overwritten
+        r, d = self.local[b]
+        return r[i], d[i]
+
+    def step_done(self, t):
+        """Call after step t was enqueued; launches the chunk's gather when t closes a chunk."""
+        if t % self.C == self.C - 1:
+            self._launch((t // self.C) & 1)
+
+    def flush(self, t_next):
+        """Gather a partly filled last chunk (steps up to t_next - 1)."""
+        if t_next % self.C:
+            self._launch((t_next // self.C) & 1)
+
+    def _launch(self, b):
+        if not self.collective:
+            return
+        import torch.distributed as dist
+
+        (lr, ld), (gr, gd) = self.local[b], self.glob[b]
+        # (the output as the concatenation along dim 0 that every backend accepts; [world, C, ...] is a view of it)
+        w1 = dist.all_gather_into_tensor(gr.view((self.world * self.C,) + tuple(lr.shape[1:])), lr, group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(gd.view((self.world * self.C,) + tuple(ld.shape[1:])), ld, group=self.group, async_op=True)
+        self.pending[b] = (w1, w2)
+
+    def wait(self, b=None):
+        for s in ((0, 1) if b is None else (b,)):
+            if self.pending[s] is not None:
+                for w in self.pending[s]:
+                    w.wait()
+                self.pending[s] = None
+
+    def result(self, chunk_index):
+        """-> (rewards [world, C, E, N], done [world, C, E]) of a gathered chunk (rank-major = global env order)."""
+        b = chunk_index & 1
+        self.wait(b)
+        if not self.collective:
+            r, d = self.local[b]
+            return r[None], d[None]
+        return self.glob[b]
 
 
 def max_over_ranks(value, device, world):

@@ -53,6 +53,27 @@ def _worker(rank, world, port, q):
             want_r = torch.arange(0, world * E, dtype=torch.float32)[:, None].repeat(1, N) * 10 + t
             want_d = ((torch.arange(0, world * E) + t) % 3 == 0).to(torch.uint8)
             assert torch.equal(gr, want_r) and torch.equal(gd, want_d)
+        # the chunked variant bench.py uses: steps write straight into the chunk buffer, one gather per 4 steps, a partial last chunk
+        cg = sh.ChunkedRolloutGather(E, N, torch.device("cpu"), world, chunk=4)
+        T = 10
+        got = {}
+        for t in range(T):
+            r, d = cg.views(t)
+            r.copy_(torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, N) * 10 + t)
+            d.copy_(((torch.arange(lo, hi) + t) % 3 == 0).to(torch.uint8))
+            cg.step_done(t)
+            if t % 4 == 3:
+                gr, gd = cg.result(t // 4)
+                got[t // 4] = (gr.clone(), gd.clone())
+        cg.flush(T)
+        gr, gd = cg.result(T // 4)
+        got[T // 4] = (gr.clone(), gd.clone())
+        for t in range(T):
+            gr, gd = got[t // 4]
+            assert gr.shape == (world, 4, E, N)
+            want_r = torch.arange(0, world * E, dtype=torch.float32)[:, None].repeat(1, N) * 10 + t
+            want_d = ((torch.arange(0, world * E) + t) % 3 == 0).to(torch.uint8)
+            assert torch.equal(gr[:, t % 4].reshape(world * E, N), want_r) and torch.equal(gd[:, t % 4].reshape(world * E), want_d)
         slow = sh.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
         assert slow == float(world)
         q.put((rank, "ok"))
