@@ -1162,16 +1162,23 @@ __global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, ui
         for (int q = lane; q < (row + 3) / 4; q += WAVE) {
             const int f0 = 4 * q;
             const int i0 = (int)fdiv((uint32_t)f0, cfg.div_gg_row), d0 = f0 - i0 * GG;
-            uint32_t word;
-            if (DWORDS && d0 + 3 < GG) {
-                // the four bytes lie in one agent's row: two aligned dwords of its map, funnel-shifted to d0
+            if (DWORDS) {
+                // bytes d0 .. d0 + 3 of agent i0's row: two aligned dwords of its map, funnel-shifted (past the row's end the
+                // map's padding shows up and is masked off below)
                 const uint32_t* m32 = (const uint32_t*)(maps + ((slot_pack >> (2 * i0)) & 3u) * MS);
-                word = __builtin_amdgcn_alignbyte(m32[(d0 >> 2) + 1], m32[d0 >> 2], (uint32_t)(d0 & 3));
+                uint32_t word = __builtin_amdgcn_alignbyte(m32[(d0 >> 2) + 1], m32[d0 >> 2], (uint32_t)(d0 & 3));
                 const uint32_t sd = (uint32_t)((int)selfc[i0] - d0);
                 if (sd < 4u) word |= 0x80u << (8 * sd);
+                const int nb = GG - d0;  // bytes left in this agent's row
+                if (nb < 4) {            // the dword runs into the next agent's row (never past the env: N * GG is a multiple of 4)
+                    const int i1 = i0 + 1;
+                    uint32_t nxt = *(const uint32_t*)(maps + ((slot_pack >> (2 * i1)) & 3u) * MS);
+                    const uint32_t s1 = selfc[i1];
+                    if (s1 < (uint32_t)(4 - nb)) nxt |= 0x80u << (8 * s1);
+                    word = (word & ((1u << (8 * nb)) - 1u)) | (nxt << (8 * nb));
+                }
                 ((uint32_t*)out)[q] = word;
             } else {
-                word = 0;
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const int f = f0 + b;
@@ -1179,11 +1186,9 @@ __global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, ui
                         const int i = (d0 + b >= GG) ? i0 + 1 : i0, d = (d0 + b >= GG) ? d0 + b - GG : d0 + b;
                         uint32_t v = maps[((slot_pack >> (2 * i)) & 3u) * MS + d];
                         if (d == (int)selfc[i]) v |= 0x80u;
-                        if (DWORDS) word |= v << (8 * b);
-                        else out[f] = (uint8_t)v;
+                        out[f] = (uint8_t)v;
                     }
                 }
-                if (DWORDS) ((uint32_t*)out)[q] = word;
             }
         }
         __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
