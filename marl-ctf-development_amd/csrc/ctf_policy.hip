@@ -89,9 +89,10 @@ __device__ __forceinline__ PolCodes<NP> pol_load_codes(const uint8_t* cp, int la
 
 // Loads the compiler does not track (the idiom of k_observe): left to itself it sinks a "prefetch" down to its first use, i.e.
 // BEHIND the sample's stores, and then waits with vmcnt(0) — which also drains every one of those stores before the next
-// sample may start.  Issued by hand at the top of a sample and waited for with a COUNTED vmcnt (the counter retires in
-// issue order; the stores issued since are younger), the next sample's inputs arrive while this one computes and the
-// stores keep draining in the background.
+// sample may start.  Issued by hand at the top of a sample and waited for, at the END OF THE SAME ITERATION, with a COUNTED
+// vmcnt (the counter retires in issue order; the stores issued since are younger), the next sample's inputs arrive while
+// this one computes and the stores keep draining in the background.  (Waiting at the top of the NEXT iteration is a bug:
+// the compiler may copy the destination registers at the back edge, before the data has landed.)
 __device__ __forceinline__ uint32_t pol_async_ubyte(const uint8_t* ptr) {
     uint32_t v;
     asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
@@ -187,10 +188,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         uint16_t* arow = a.act + (size_t)((POL_ABLATE & 16) ? s_first : s) * a.Kp;
         uint32_t two = 0;
         if (FAST) {
-            // the loads below are older than the 1 + 4 T2 stores of the previous sample: a counted wait leaves those in flight
-            constexpr int STORES = 1 + 4 * ((((TG - 4) * (TG - 4)) + 31) >> 5);
-            static_assert(NP <= 4, "POL_WAIT_VM ties four code registers");
-            if (POL_ABLATE == 0) POL_WAIT_VM(STORES, nextc.b[0], nextc.b[NP > 1 ? 1 : 0], nextc.b[NP > 2 ? 2 : 0], nextc.b[NP > 3 ? 3 : 0], nextm);
             const PolCodes<NP> cur = nextc;
             two = nextm;
             {   // next sample's inputs (the last sample re-reads itself: every lane always issues the same loads)
@@ -338,6 +335,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        if (FAST && POL_ABLATE == 0) {
+            // The next sample's inputs, issued at the top of this sample, are older than its 1 + 4 T2 stores: a counted wait
+            // leaves those stores in flight.  The wait sits HERE, in the iteration that issued the loads — the compiler knows
+            // nothing about their latency and is free to copy the destination registers at the loop's back edge.
+            constexpr int STORES = 1 + 4 * ((((TG - 4) * (TG - 4)) + 31) >> 5);
+            static_assert(NP <= 4, "POL_WAIT_VM ties four code registers");
+            POL_WAIT_VM(STORES, nextc.b[0], nextc.b[NP > 1 ? 1 : 0], nextc.b[NP > 2 ? 2 : 0], nextc.b[NP > 3 ? 3 : 0], nextm);
+        }
     }
 }
 

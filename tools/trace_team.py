@@ -33,7 +33,7 @@ for t in range(10):
 codes, meta = vec.observe_codes()
 net = pkg.policy_native.CtfPolicyNative(9, vec.N_CHANNELS, 15, vec.META_LEN).cuda().prepare()
 for _ in range(3):
-    net.features_from_codes(codes, meta, [0, 1, 2, 3], shared_view=True, self_cells=vec.self_cells)
+    net.features_from_codes(codes, meta, [i for i in range(8) if vec.AGENT_TEAMS[i] == 0], shared_view=True, self_cells=vec.self_cells)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(so)
 buf = (ctypes.c_uint64 * (16 * 64))()
