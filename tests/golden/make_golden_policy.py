@@ -28,29 +28,32 @@ def main():
     finally:
         sys.path[:] = saved
         sys.modules.pop("agent_network", None)
-    random.seed(5)
-    np.random.seed(5)
-    env = Ref(SCENARIO=scn.arena_iii, **mg.ARENA_KW)
-    dims = env.get_env_dims()
-    rng = np.random.default_rng(3)
-    grids, metas, masks = [], [], []
-    for t in range(12):
-        env.step([int(a) for a in rng.integers(0, 9, env.N_AGENTS)])
-        for i in range(env.N_AGENTS):
-            grids.append(env.standardise_state(i, reverse_grid=env.AGENT_TEAMS[i] == 1)[0])
-            metas.append(env.get_env_metadata(i)[0])
-            masks.append(env.AGENT_TYPE_ACTION_MASK[env.AGENT_TYPES[i]])
-    grids, metas, masks = np.stack(grids), np.stack(metas), np.array(masks, np.float32)
-    net = fill_(ref_net.Agent(9, dims[0][0], env.GRID_SIZE, dims[2][0]))
-    with torch.no_grad():
-        g, m, k = torch.tensor(grids, dtype=torch.float32), torch.tensor(metas, dtype=torch.float32), torch.tensor(masks)
-        value, logits = net(g, m)
-        actions = logits.argmax(dim=1)
-        _, logprob, entropy, value2 = net.get_action_and_value(g, m, k, action=actions % 5)
-    np.savez_compressed(os.path.join(HERE, "policy_arena.npz"), grids=np.packbits(grids.reshape(-1)), grid_shape=np.array(grids.shape),
-                        metas=metas.view(np.uint16), masks=masks, value=value.numpy(), logits=logits.numpy(),
-                        actions=(actions % 5).numpy(), logprob=logprob.numpy(), entropy=entropy.numpy())
-    print("samples", len(grids), "value range", float(value.min()), float(value.max()), "per-logit std over samples", logits.std(dim=0).numpy().round(3))
+    for name, scenario, kw in (("policy_arena", "arena_iii", mg.ARENA_KW), ("policy_split", "arrow", mg.SPLIT_KW)):
+        random.seed(5)
+        np.random.seed(5)
+        env = Ref(SCENARIO=getattr(scn, scenario), **kw)
+        dims = env.get_env_dims()
+        rng = np.random.default_rng(3)
+        grids, metas, masks = [], [], []
+        for t in range(12):
+            env.step([int(a) for a in rng.integers(0, 9, env.N_AGENTS)])
+            for i in range(env.N_AGENTS):
+                grids.append(env.standardise_state(i, reverse_grid=env.AGENT_TEAMS[i] == 1)[0])
+                metas.append(env.get_env_metadata(i)[0])
+                masks.append(env.AGENT_TYPE_ACTION_MASK[env.AGENT_TYPES[i]])
+        grids, metas, masks = np.stack(grids), np.stack(metas), np.array(masks, np.float32)
+        net = fill_(ref_net.Agent(9, dims[0][0], env.GRID_SIZE, dims[2][0]))
+        with torch.no_grad():
+            g, m, k = torch.tensor(grids, dtype=torch.float32), torch.tensor(metas, dtype=torch.float32), torch.tensor(masks)
+            value, logits = net(g, m)
+            actions = logits.argmax(dim=1)
+            _, logprob, entropy, value2 = net.get_action_and_value(g, m, k, action=actions % 5)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), grids=np.packbits(grids.reshape(-1)), grid_shape=np.array(grids.shape),
+                            metas=metas.view(np.uint16), masks=masks, value=value.numpy(), logits=logits.numpy(),
+                            actions=(actions % 5).numpy(), logprob=logprob.numpy(), entropy=entropy.numpy(),
+                            n_agents=np.array(env.N_AGENTS))
+        print(name, "samples", len(grids), "value range", float(value.min()), float(value.max()), "per-logit std over samples",
+              logits.std(dim=0).numpy().round(3))
 
 
 if __name__ == "__main__":

@@ -54,17 +54,20 @@ def unpermute(net, feats):
     return out
 
 
-def _golden():
-    z = np.load(os.path.join(GOLDEN, "policy_arena.npz"))
+GOLDEN_POLICIES = ("policy_arena", "policy_split")  # outputs of the reference's own Agent on 8_arena (G = 15) / 0_the_split (G = 11)
+
+
+def _golden(name="policy_arena"):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
     shape = tuple(int(x) for x in z["grid_shape"])
     grids = np.unpackbits(z["grids"])[: int(np.prod(shape))].reshape(shape)  # [T*N, C, G, G], step-major
     metas = z["metas"].view(np.float16)
-    n = 8
-    return z, grids, metas, n
+    return z, grids, metas, int(z["n_agents"])
 
 
-def test_features_match_the_emulation_and_the_float32_network_on_reference_observations():
-    z, grids, metas, n = _golden()
+@pytest.mark.parametrize("golden", GOLDEN_POLICIES)
+def test_features_match_the_emulation_and_the_float32_network_on_reference_observations(golden):
+    z, grids, metas, n = _golden(golden)
     T = grids.shape[0] // n
     c, g = grids.shape[1], grids.shape[2]
     net = fill_(native.CtfPolicyNative(9, c, g, metas.shape[1])).cuda()
@@ -83,8 +86,8 @@ def test_features_match_the_emulation_and_the_float32_network_on_reference_obser
         ref32 = torch.cat((x.flatten(1), torch.tensor(metas).float()), dim=1).double()
     assert float((got - ref32).abs().max()) < 3e-2  # bf16 operands vs the float32 network, activations in [-1, 1]
     # a subset of agents, in another order: the same rows
-    sub = net.features_from_codes(codes, meta, [5, 1])
-    assert torch.equal(sub[:T], feats[5 * T:6 * T]) and torch.equal(sub[T:], feats[T:2 * T])
+    sub = net.features_from_codes(codes, meta, [n - 1, 1])
+    assert torch.equal(sub[:T], feats[(n - 1) * T:n * T]) and torch.equal(sub[T:], feats[T:2 * T])
 
 
 @pytest.mark.parametrize("g,c,n,e", [(11, 8, 4, 70), (15, 14, 8, 33), (20, 14, 8, 9), (7, 5, 2, 130), (32, 15, 3, 5)])
@@ -104,8 +107,9 @@ def test_features_on_random_codes_for_other_grid_sizes(g, c, n, e):
     assert float((got - want).abs().max()) <= 2.0 ** -7
 
 
-def test_native_inference_is_close_to_the_reference_agent_and_respects_the_mask():
-    z, grids, metas, n = _golden()
+@pytest.mark.parametrize("golden", GOLDEN_POLICIES)
+def test_native_inference_is_close_to_the_reference_agent_and_respects_the_mask(golden):
+    z, grids, metas, n = _golden(golden)
     T = grids.shape[0] // n
     c, g = grids.shape[1], grids.shape[2]
     net = fill_(native.CtfPolicyNative(9, c, g, metas.shape[1])).cuda()
