@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/ctf_policy.h"
 
@@ -27,7 +28,7 @@
 // Profiling-only ablations (never defined in the shipped build; tools/ablate_policy.sh):
 //   bit0 no activation stores, bit1 no exp/rcp in tanh, bit2 no h0 update, bit3 every operand read from one LDS address,
 //   bit4 every sample of a wave stored to the same row (store instructions without the HBM traffic),
-//   bit5 team kernel: half of the shared activation stores skipped
+//   bit5 team kernel: half of the shared activation stores skipped, bit6 team kernel: rows env-major
 #ifndef POL_ABLATE
 #define POL_ABLATE 0
 #endif
@@ -387,7 +388,7 @@ struct TeamArgs {
 };
 
 template <int TG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_policy_features_team(TeamArgs ta) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_policy_features_team(TeamArgs ta) {
     extern __shared__ uint32_t lds[];
     const PolicyArgs& a = ta.p;
     constexpr int G = TG, G1 = G - 2, G2 = G - 4, GG = G * G, P1 = G1 * G1, P2 = G2 * G2, PP = ((P2 + 31) >> 5) << 5;
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int npair = (a.Kp - 32 * PP) >> 1;
     const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
     const int ag0 = (int)(a.sel_pack & 15u);
-    const size_t agent_stride = (size_t)a.n_envs * a.Kp * 2;  // bytes from agent k's rows to agent k + 1's
+    const size_t agent_stride = ((POL_ABLATE & 64) ? (size_t)1 : (size_t)a.n_envs) * a.Kp * 2;  // bytes from agent k's rows to agent k + 1's
 
     PolCodes<NP> oldc, nextc;
 #pragma unroll
@@ -475,25 +476,48 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         __builtin_amdgcn_wave_barrier();
         POL_STAMP(1);
 
-        // ---- shared conv1 + tanh -> h1   (one tile at a time: registers are the scarce resource here, and with three waves per
-        // SIMD a second accumulator chain per wave bought nothing in k_policy_features)
+        // ---- shared conv1 + tanh -> h1, two tiles in flight (the launch runs one wave per SIMD — see the launcher — so
+        // registers are plentiful and the wave's own instruction-level parallelism is all there is)
         constexpr int T1 = (P1 + 15) >> 4;
         int x1 = x1_0, cell1 = y1_0 * G + x1_0;
+        int t = 0;
 #pragma unroll 1
-        for (int t = 0; t < T1; t++) {
-            const uint8_t* base = h0 + cell1 * 16;
+        for (; t + 1 < T1; t += 2) {
+            const uint8_t* base_a = h0 + cell1 * 16;
             x1 += dx1;
             cell1 += dy1 * G + dx1;
             if (x1 >= G1) { x1 -= G1; cell1 += G - G1; }
-            f32x4_t acc = bias1;
+            const uint8_t* base_b = h0 + cell1 * 16;
+            x1 += dx1;
+            cell1 += dy1 * G + dx1;
+            if (x1 >= G1) { x1 -= G1; cell1 += G - G1; }
+            f32x4_t acc_a = bias1, acc_b = bias1;
 #pragma unroll
             for (int q = 0; q < 5; q++) {
-                const u32x4_t b = *(const u32x4_t*)(base + off1[q]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w1[q]), as_bf16x8(b), acc, 0, 0, 0);
+                const u32x4_t ba = *(const u32x4_t*)(base_a + off1[q]);
+                const u32x4_t bb = *(const u32x4_t*)(base_b + off1[q]);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w1[q]), as_bf16x8(ba), acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w1[q]), as_bf16x8(bb), acc_b, 0, 0, 0);
             }
             u32x2_t o;
-            o[0] = tanh2_pack(acc[0], acc[1]);
-            o[1] = tanh2_pack(acc[2], acc[3]);
+            o[0] = tanh2_pack(acc_a[0], acc_a[1]);
+            o[1] = tanh2_pack(acc_a[2], acc_a[3]);
+            *(u32x2_t*)(h1w + 16 * t * 16) = o;
+            o[0] = tanh2_pack(acc_b[0], acc_b[1]);
+            o[1] = tanh2_pack(acc_b[2], acc_b[3]);
+            *(u32x2_t*)(h1w + 16 * (t + 1) * 16) = o;
+        }
+        if (t < T1) {
+            const uint8_t* base_a = h0 + cell1 * 16;
+            f32x4_t acc_a = bias1;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const u32x4_t ba = *(const u32x4_t*)(base_a + off1[q]);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w1[q]), as_bf16x8(ba), acc_a, 0, 0, 0);
+            }
+            u32x2_t o;
+            o[0] = tanh2_pack(acc_a[0], acc_a[1]);
+            o[1] = tanh2_pack(acc_a[2], acc_a[3]);
             *(u32x2_t*)(h1w + 16 * t * 16) = o;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -501,29 +525,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         POL_STAMP(2);
 
         // ---- shared conv2 + tanh -> EVERY agent's row, all positions; the agent's 5 x 5 patch is overwritten below
-        uint8_t* const act_env = (uint8_t*)a.act + (size_t)e * a.Kp * 2;  // agent 0's row of this env (uniform)
+        uint8_t* const act_env = (uint8_t*)a.act + ((POL_ABLATE & 64) ? (size_t)e * A : (size_t)e) * a.Kp * 2;  // agent 0's row of this env (uniform)
         constexpr int T2 = (P2 + 31) >> 5;
+        static_assert((T2 & 1) == 0, "tile pairs");
 #pragma unroll 1
-        for (int t2 = 0; t2 < T2; t2++) {
-            const int p = 32 * t2 + n2, pc = min(p, P2 - 1);
-            const int y = (int)(((uint32_t)pc * a.inv_g2) >> 16), x = pc - y * G2;
-            const uint8_t* base = h1 + (y * G1 + x) * 16 + hh * H1A;
-            f32x16_t acc = bias2;
+        for (int t2 = 0; t2 < T2; t2 += 2) {
+            const int pa = 32 * t2 + n2, pb = pa + 32;
+            const int pca = min(pa, P2 - 1), pcb = min(pb, P2 - 1);
+            const int ya = (int)(((uint32_t)pca * a.inv_g2) >> 16), yb = (int)(((uint32_t)pcb * a.inv_g2) >> 16);
+            const uint8_t* base_a = h1 + (ya * G1 + (pca - ya * G2)) * 16 + hh * H1A;
+            const uint8_t* base_b = h1 + (yb * G1 + (pcb - yb * G2)) * 16 + hh * H1A;
+            f32x16_t acc_a = bias2, acc_b = bias2;
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
-                const u32x4_t b = *(const u32x4_t*)(base + ((tap / 3) * G1 + (tap % 3)) * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(b), acc, 0, 0, 0);
+                const int off = ((tap / 3) * G1 + (tap % 3)) * 16;
+                const u32x4_t ba = *(const u32x4_t*)(base_a + off);
+                const u32x4_t bb = *(const u32x4_t*)(base_b + off);
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(ba), acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[tap]), as_bf16x8(bb), acc_b, 0, 0, 0);
             }
-            {   // every lane stores (also the positions past P2 of the last tile: finite values under zero fc1 weights): whole lines
-                const uint32_t lane_off = (uint32_t)(((3 + hh) * PP + p) * 8);  // the four channel groups sit (2 q - 3) * PP * 8 around it
+            // every lane stores (also the positions past P2 of the last tile: finite values under zero fc1 weights): whole lines
+            const uint32_t lane_off = (uint32_t)(((3 + hh) * PP + pa) * 8);  // the four channel groups sit (2 q - 3) * PP * 8 around it
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    u32x2_t o;
-                    o[0] = tanh2_pack(acc[4 * q], acc[4 * q + 1]);
-                    o[1] = tanh2_pack(acc[4 * q + 2], acc[4 * q + 3]);
+            for (int q = 0; q < 4; q++) {
+                u32x2_t oa, ob;
+                oa[0] = tanh2_pack(acc_a[4 * q], acc_a[4 * q + 1]);
+                oa[1] = tanh2_pack(acc_a[4 * q + 2], acc_a[4 * q + 3]);
+                ob[0] = tanh2_pack(acc_b[4 * q], acc_b[4 * q + 1]);
+                ob[1] = tanh2_pack(acc_b[4 * q + 2], acc_b[4 * q + 3]);
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (k < A && !((POL_ABLATE & 32) && (q & 1))) *(u32x2_t*)(act_env + k * agent_stride + lane_off + (2 * q - 3) * PP * 8) = o;
+                for (int k = 0; k < 4; k++) {
+                    if (k < A && !((POL_ABLATE & 32) && (q & 1))) {
+                        *(u32x2_t*)(act_env + k * agent_stride + lane_off + (2 * q - 3) * PP * 8) = oa;
+                        *(u32x2_t*)(act_env + k * agent_stride + lane_off + (2 * q - 3) * PP * 8 + 256) = ob;
+                    }
                 }
             }
         }
@@ -859,10 +894,18 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
     const int per_wave = pol_h0_bytes(grid_size) + pol_h1_bytes(grid_size);
     int wpb = 4;
     while (wpb > 1 && wpb * per_wave > 64 * 1024) wpb >>= 1;
+    if (const char* ov = getenv("CTF_POLICY_WPB")) {  // profiling only
+        const int v = atoi(ov);
+        if (v >= 1 && v <= wpb) wpb = v;
+    }
     const size_t sh = (size_t)wpb * per_wave;
     int per_cu = (int)((160 * 1024) / sh);
     if (per_cu < 1) per_cu = 1;
     if (per_cu * wpb > 12) per_cu = 12 / wpb;  // 3 waves per SIMD: what the register budget allows
+    if (const char* ov = getenv("CTF_POLICY_BLOCKS_PER_CU")) {  // profiling only: occupancy scaling
+        const int v = atoi(ov);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
     const int S = n_envs * n_sel;
     int blocks = (S + wpb - 1) / wpb;
     if (blocks > n_cus * per_cu) blocks = n_cus * per_cu;
@@ -874,8 +917,14 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
         ta.p = a;
         ta.selfcells = shared_view_selfcell_dev;
         ta.A = n_sel;
+        // ONE block per CU, one wave per SIMD: measured 1.12 ms for the two teams of an arena step against 1.32 / 1.36 with two /
+        // three blocks — every wave of this kernel keeps A activation rows open at once, and the more such streams a CU runs
+        // the worse its store path does (the per-agent kernel, one row per wave, is the other way round: 1.80 / 1.57 / 1.51)
+        int team_per_cu = 1;
+        if (const char* ov = getenv("CTF_POLICY_BLOCKS_PER_CU")) team_per_cu = atoi(ov) >= 1 ? atoi(ov) : 1;  // profiling only
+        if (team_per_cu > per_cu) team_per_cu = per_cu;
         int tblocks = (n_envs + wpb - 1) / wpb;
-        if (tblocks > n_cus * per_cu) tblocks = n_cus * per_cu;
+        if (tblocks > n_cus * team_per_cu) tblocks = n_cus * team_per_cu;
         if (grid_size == 15) {
             if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_features_team<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             if (err == hipSuccess) hipLaunchKernelGGL(k_policy_features_team<15>, dim3(tblocks), dim3(wpb * WAVE), sh, st, ta);

@@ -1,10 +1,27 @@
+#!/bin/bash
+# HBM traffic of the policy front kernels at a given occupancy (profiling only): bash tools/profile_team.sh <blocks_per_cu>
 set -o pipefail
-OUT=$PWD/gpurun_out/prof_team
+B=${1:-3}
+OUT=$PWD/gpurun_out/prof_team_b$B
 mkdir -p $OUT
 export TMPDIR=/tmp
+export CTF_POLICY_BLOCKS_PER_CU=$B
 CMD="$PWD/tools/policy_native_bench.py 65536"
 cd /tmp
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $CMD > $OUT/pmc_sq.log 2>&1 || echo "pmc sq failed"
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 $CMD > $OUT/pmc_sq2.log 2>&1 || echo "pmc sq2 failed"
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq3 -- python3 $CMD > $OUT/pmc_sq3.log 2>&1 || echo "pmc sq3 failed"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $CMD > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $CMD > $OUT/pmc_write.log 2>&1 || echo "pmc write failed"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $CMD > $OUT/pmc_sq.log 2>&1 || echo "pmc sq failed"
+python3 - <<PY
+import csv,glob,collections
+for p in ("pmc_fetch","pmc_write","pmc_sq"):
+    f=glob.glob("$OUT/"+p+"/**/*_counter_collection.csv",recursive=True)
+    if not f: print(p,"missing"); continue
+    vals=collections.defaultdict(lambda: collections.defaultdict(list)); dur=collections.defaultdict(dict)
+    for r in csv.DictReader(open(f[0])):
+        k=r["Kernel_Name"]
+        if "k_policy_features" not in k: continue
+        key=("team" if "team" in k else "agent")
+        vals[key][r["Counter_Name"]].append(float(r["Counter_Value"])); dur[key][r["Dispatch_Id"]]=int(r["End_Timestamp"])-int(r["Start_Timestamp"])
+    for key in vals:
+        print("blocks/CU $B", p, key, "dur_us", round(sum(dur[key].values())/len(dur[key])/1e3,1), {c:round(sum(v)/len(v)) for c,v in vals[key].items()})
+PY
