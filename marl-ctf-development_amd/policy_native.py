@@ -103,6 +103,8 @@ class CtfPolicyNative(CtfPolicy):
         self._prep = None
         self._seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)  # Philox key of the action sampler
         self._calls = 0                                                                    # ... and its running offset
+        self._act_bufs = {}        # persistent activation matrices of act_from_codes, by (rows, row length, device)
+        self.placement_probe_ms = None
 
     # -- weights in the kernels' / the GEMM's layouts ----------------------------------------------
     def prepare(self):
@@ -175,6 +177,40 @@ class CtfPolicyNative(CtfPolicy):
             raise _abi.CtfLibraryError("ctf_policy_features: " + (p["lib"].ctf_policy_last_error() or b"").decode())
         return out
 
+    def _features_tuned(self, codes, meta, agent_idx, shared_view, self_cells, tries=6, good_enough=0.9):
+        """features_from_codes into a persistent activation buffer.  About half of all >1 GiB allocations on this pool stream
+        ~20 % slower for both the kernel's stores and the GEMM's reads ("Allocation placement"): on first use a
+        few candidate buffers are timed with the real work (front kernel + fc1 GEMM) and a fast one is kept."""
+        p = self._ready()
+        rows = len(agent_idx) * int(codes.shape[0])
+        key = (rows, p["kp"], codes.device.index)
+        buf = self._act_bufs.get(key)
+        if buf is not None:
+            return self.features_from_codes(codes, meta, agent_idx, out=buf, shared_view=shared_view, self_cells=self_cells)
+
+        def probe(cand):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(3):
+                if i == 1:
+                    a.record()
+                self.features_from_codes(codes, meta, agent_idx, out=cand, shared_view=shared_view, self_cells=self_cells)
+                torch.nn.functional.linear(cand, p["fc1_w"], p["fc1_b"])
+            b.record()
+            b.synchronize()
+            return a.elapsed_time(b) / 2
+
+        new = lambda: torch.empty((rows, p["kp"]), dtype=torch.bfloat16, device=codes.device)
+        cands = [new()]
+        times = [probe(cands[0])] if rows * p["kp"] * 2 > (256 << 20) else [0.0]
+        while 0.0 < min(times) and len(cands) < tries and min(times) > good_enough * max(times):  # both kinds seen: stop
+            cands.append(new())  # rejected candidates stay allocated meanwhile, so that new ones land elsewhere
+            times.append(probe(cands[-1]))
+        buf = cands[times.index(min(times))]
+        self._act_bufs[key] = buf
+        self.placement_probe_ms = times
+        del cands
+        return self.features_from_codes(codes, meta, agent_idx, out=buf, shared_view=shared_view, self_cells=self_cells)
+
     def _tail(self, feats, mask=None, given=None, want_logits=False):
         """fc1 (bf16 GEMM) then the fused tail -> (action int32, logprob, entropy, value, logits or None), each [B]."""
         p = self._ready()
@@ -215,6 +251,6 @@ class CtfPolicyNative(CtfPolicy):
         """get_action_and_value (agent_network.py:63-81) for agents ``agent_idx`` of every env, from the compact observation:
         -> (action int32 [B], log_prob [B], entropy [B], value [B, 1]).  Sampling: inverse CDF of the masked softmax with one
         Philox4x32-10 uniform per sample, keyed by this module's seed and call count."""
-        feats = self.features_from_codes(codes, meta, agent_idx, shared_view=shared_view, self_cells=self_cells)
+        feats = self._features_tuned(codes, meta, agent_idx, shared_view, self_cells)
         act, logprob, entropy, value, _ = self._tail(feats, mask=masking_decision_tensor, given=action)
         return act, logprob, entropy, value.reshape(-1, 1)
