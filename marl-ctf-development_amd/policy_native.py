@@ -106,6 +106,11 @@ class CtfPolicyNative(CtfPolicy):
         self._act_bufs = {}        # persistent activation matrices of act_from_codes, by (rows, row length, device)
         self.placement_probe_ms = None
 
+    def __getstate__(self):  # copies / pickles carry the parameters, not the kernel-side operands or device buffers
+        d = dict(self.__dict__)
+        d["_prep"], d["_act_bufs"] = None, {}
+        return d
+
     # -- weights in the kernels' / the GEMM's layouts ----------------------------------------------
     def prepare(self):
         dev = self.conv1.weight.device

@@ -132,3 +132,18 @@ def test_policy_kernel_operands_follow_the_documented_lane_maps():
             for j in range(8):
                 assert abs(th[st, l, j] - head[l & 15, 32 * st + 8 * (l >> 4) + j]) < 1e-6
     assert np.allclose(tb2, bf2 * s) and np.allclose(tbh[:9], ba) and np.allclose(tbh[9], bv[0]) and not tbh[10:].any()
+
+
+def test_native_policy_module_copies_and_pickles_without_its_device_side_state():
+    import copy
+    import pickle
+
+    import torch
+
+    native = importlib.import_module("marl-ctf-development_amd.policy_native")
+    net = native.CtfPolicyNative(9, 14, 15, 22, seed=5)
+    net._prep = {"lib": object(), "stamp": None}      # stands for the ctypes handle and device operands
+    net._act_bufs = {(1, 2, 0): torch.zeros(1)}
+    for clone in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+        assert clone._prep is None and clone._act_bufs == {} and clone._seed == 5
+        assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), net.state_dict().values()))
