@@ -1294,6 +1294,10 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     // the CU's 32-wave limit, grid-stride beyond that; a few block slots stay free so that a concurrent small kernel
     // (the RCCL all-gather of the rollout tensors) can start beside this launch instead of behind it
     int cap = n_cus * (32 / wpb);
+    if (const char* ov = getenv("CTF_OBS_BLOCKS_PER_CU")) {  // profiling only: occupancy scaling of the render
+        const int v = atoi(ov);
+        if (v >= 1 && v < 32 / wpb) cap = n_cus * v;
+    }
     if (cap > 64) cap -= obs_reserve_blocks();
     if (blocks > cap) blocks = cap;
     const dim3 grid(blocks), block(wpb * WAVE);
