@@ -76,7 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
-    ap.add_argument("--workload", choices=["arena", "split"], default="arena")
+    ap.add_argument("--workload", choices=["arena", "split", "arena20"], default="arena",
+                    help="arena: 8_arena on the reference's 15x15 arena_iii (the headline); split: 0_the_split, use with "
+                         "--envs-per-gpu 4096; arena20: the 8_arena agents and rules on a synthetic 20x20 map")
     ap.add_argument("--no-metrics", action="store_true", help="compile the reference's metric counters out of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-exchange", action="store_true",
@@ -112,6 +114,9 @@ def main():
     if args.workload == "arena":
         kwargs = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
         label = "8_arena (arena_iii 15x15, 4v4 heterogeneous)"
+    elif args.workload == "arena20":
+        kwargs = dict(pkg.configs.ARENA20_KWARGS, SCENARIO=pkg.configs.arena20_scenario())
+        label = "8_arena agents and rules on a synthetic 20x20 map (4v4 heterogeneous)"
     else:
         kwargs = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow)
         label = "0_the_split (arrow 11x11, 2v2)"

@@ -39,3 +39,43 @@ ARENA_KWARGS = {  # 8_arena: arena_iii map, 4v4 heterogeneous
     "GUARDIAN_DAMAGE_MULTIPLIER": 5.0,
     "VAULT_HP_COST": 1.25,
 }
+
+
+# BASELINE.json words the target as "8_arena (4v4, 20x20 grid)"; the reference's arena maps are 15x15.  For that wording:
+# the 8_arena agent table and rules on a SYNTHETIC point-symmetric 20x20 map of this build's own (the same map the
+# syn_arena20 golden trajectory was recorded on from the reference env).  bench.py --workload arena20.
+ARENA20_ROWS = (
+    "....................",
+    "....................",
+    "....................",
+    "##......+#.#+.......",
+    "....................",
+    "....#.....+.........",
+    "......+......+......",
+    "...............#....",
+    "........+......#....",
+    "++.......#..........",
+    "..........#.......++",
+    "....#......+........",
+    "....#...............",
+    "......+......+......",
+    ".........+.....#....",
+    "....................",
+    ".......+#.#+......##",
+    "....................",
+    "....................",
+    "....................",
+)
+
+
+def arena20_scenario():
+    try:
+        from .maps import _scenario
+    except ImportError:  # pragma: no cover
+        from maps import _scenario
+    return _scenario("SynArena20", None, ARENA20_ROWS, flags=((3, 10), (16, 9)), captures=((3, 10), (16, 9)),
+                     spawns=((7, 17), (12, 2)),
+                     starts=((7, 16), (12, 3), (8, 17), (11, 2), (6, 17), (13, 2), (7, 18), (12, 1)))
+
+
+ARENA20_KWARGS = dict(ARENA_KWARGS, GRID_SIZE=20)
