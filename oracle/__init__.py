@@ -76,7 +76,10 @@ class OracleEnv:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().octf_destroy(self._h)
+            try:
+                lib().octf_destroy(self._h)
+            except TypeError:  # interpreter shutdown: the module's globals are already gone
+                pass
             self._h = None
 
     def seed(self, py_seed, np_seed):
