@@ -8,3 +8,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The suites need the in-tree libraries (HIP ABI + CPU oracle).  They normally arrive built; build them when missing."""
+    hip = os.path.join(ROOT, "marl-ctf-development_amd", "csrc", "libctf_hip.so")
+    orc = os.path.join(ROOT, "oracle", "libctf_oracle.so")
+    if not (os.path.exists(hip) and os.path.exists(orc)):
+        import __graft_entry__
+
+        __graft_entry__.build()
