@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")  # repo root (this script lives in tests/: it uses the oracle)
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402  (test infrastructure: this tool is a checker, not the product)
 
