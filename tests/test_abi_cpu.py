@@ -58,3 +58,15 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "ctf_oracle" not in src, f
+
+
+def test_only_tests_smoke_and_the_cpu_baseline_leg_touch_the_oracle():
+    """oracle/ is test infrastructure: outside tests/ only __graft_entry__.smoke() and bench.py's cpu_baseline may use it."""
+    allowed = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    for dirpath, dirnames, files in os.walk(ROOT):
+        dirnames[:] = [d for d in dirnames if d not in (".git", "gpurun_out", "tests", "oracle", "__pycache__", ".pytest_cache")]
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith((".py", ".sh", ".hip", ".h", ".cpp", ".c")) and path not in allowed:
+                src = open(path, errors="replace").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M) and "ctf_oracle" not in src, path
