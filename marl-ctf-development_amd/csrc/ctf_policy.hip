@@ -1,8 +1,12 @@
-// ctf_policy.hip — the convolutional front of the reference's policy / value network (agent_network.py:13-14,30-36:
-// conv3x3(C->16) tanh, conv3x3(16->32) tanh, flatten ++ metadata) for hundreds of thousands of agents per launch, fed by
-// the env's compact observation (ctf_observe_codes) instead of the 14x larger one-hot planes.
+// ctf_policy.hip — the reference's policy / value network (agent_network.py:5-81) for hundreds of thousands of agents per
+// launch, around the library's fc1 GEMM:
+//   k_policy_features        conv3x3(C->16) tanh, conv3x3(16->32) tanh, flatten ++ metadata (agent_network.py:13-14,30-36),
+//                            one wave per agent, fed by the env's compact observation (ctf_observe_codes) instead of the
+//                            14x larger one-hot planes
+//   k_policy_features_team   the same for agents that share a view: the convolutions once per env, a patch per agent
+//   k_policy_head            tanh, fc2, tanh, heads, mask, sample, log-prob, entropy (agent_network.py:37-40,63-81)
 //
-// One wave per sample, everything between the code bytes and the activation row stays on the CU:
+// k_policy_features — one wave per sample, everything between the code bytes and the activation row stays on the CU:
 //   h0  LDS bf16 [2 halves][G*G cells][8 ch]  the one-hot input, written straight from the codes (channel halves in separate
 //           arrays: a lane's 16-byte operand reads then fall on consecutive addresses across lanes — no bank conflicts)
 //   conv1 = 16x16x32 MFMAs: D[out ch][position] over K = (2 taps) x (16 in ch); A = weights, register-resident for the
@@ -15,8 +19,8 @@
 //           are permuted to this order once on the host (policy_native.py), so no transpose happens anywhere; then the M
 //           metadata values (f16 -> bf16) and padding up to Kp (a multiple of 64: rows are whole lines).
 // tanh(x) = 1 - 2 / (2^(x * 2 log2 e) + 1): the factor 2 log2 e is folded into the conv weights and biases on the host,
-// so an activation costs v_exp_f32 + v_add + v_rcp_f32 + v_fma.
-// fc1 / fc2 / heads are plain GEMMs and stay with hipBLASLt (through torch).
+// so a pair of activations costs 2 v_exp_f32, v_pk_add_f32, 2 v_rcp_f32, v_pk_fma_f32, v_cvt_pk_bf16_f32.
+// fc1 is a plain GEMM and stays with hipBLASLt (through torch).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
