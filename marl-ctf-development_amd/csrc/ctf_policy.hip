@@ -120,9 +120,20 @@ __device__ __forceinline__ PolCodes<NP> pol_async_codes(const uint8_t* cp, int l
     for (int q = 0; q < NP; q++) v.b[q] = pol_async_ubyte(cp + min(lane + WAVE * q, GG - 1));  // clamped, not predicated: every lane loads
     return v;
 }
-// wait until at most N vector-memory operations are outstanding; ties the prefetched registers to the wait
-#define POL_WAIT_VM(N, r0, r1, r2, r3, r4) \
-    asm volatile("s_waitcnt vmcnt(%c5)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "n"(N) : "memory")
+// Wait until at most CNT vector-memory operations are outstanding, tying the prefetched registers to the wait.  Every
+// register is an operand EXACTLY ONCE: listing one lvalue twice makes the compiler satisfy the duplicates with v_mov copies
+// of the load's destination placed BEFORE the s_waitcnt, i.e. copies of a register whose data has not landed (this was the
+// G = 11 bug of round 1: NP = 2 listed b[0] three times).  tools/isa_lint.py checks the compiled ISA for that pattern.
+template <int CNT, int NP>
+__device__ __forceinline__ void pol_wait_codes(PolCodes<NP>& c) {
+    static_assert(NP >= 1 && NP <= 4, "pol_wait_codes ties at most four code registers");
+    if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(c.b[0]) : "n"(CNT) : "memory");
+    else if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(%c2)" : "+v"(c.b[0]), "+v"(c.b[1]) : "n"(CNT) : "memory");
+    else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(%c3)" : "+v"(c.b[0]), "+v"(c.b[1]), "+v"(c.b[2]) : "n"(CNT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(c.b[0]), "+v"(c.b[1]), "+v"(c.b[2]), "+v"(c.b[3]) : "n"(CNT) : "memory");
+}
+// the same wait for further registers (an s_waitcnt that follows one with the same count costs nothing)
+#define POL_WAIT_VM1(N, r0) asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(r0) : "n"(N) : "memory")
 
 template <int TG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_policy_features(PolicyArgs a) {
@@ -345,8 +356,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             // leaves those stores in flight.  The wait sits HERE, in the iteration that issued the loads — the compiler knows
             // nothing about their latency and is free to copy the destination registers at the loop's back edge.
             constexpr int STORES = 1 + 4 * ((((TG - 4) * (TG - 4)) + 31) >> 5);
-            static_assert(NP <= 4, "POL_WAIT_VM ties four code registers");
-            POL_WAIT_VM(STORES, nextc.b[0], nextc.b[NP > 1 ? 1 : 0], nextc.b[NP > 2 ? 2 : 0], nextc.b[NP > 3 ? 3 : 0], nextm);
+            pol_wait_codes<STORES, NP>(nextc);
+            POL_WAIT_VM1(STORES, nextm);
         }
     }
 }
@@ -571,10 +582,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         // wait for this env's own cells / metadata and for the next env's codes, all issued before the stores.
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(scw[0]), "+v"(scw[1]), "+v"(scw[2]), "+v"(scw[3]), "+v"(metaw[0]), "+v"(metaw[1]), "+v"(metaw[2]),
-                       "+v"(metaw[3]), "+v"(nextc.b[0]), "+v"(nextc.b[NP > 1 ? 1 : 0]), "+v"(nextc.b[NP > 2 ? 2 : 0]),
-                       "+v"(nextc.b[NP > 3 ? 3 : 0])
+                       "+v"(metaw[3])
                      :
                      : "memory");
+        pol_wait_codes<0, NP>(nextc);  // every register exactly once (see pol_wait_codes)
 
         POL_STAMP(4);
         // ---- per agent: own-position bit on, the two patches, everything restored
@@ -779,7 +790,10 @@ __global__ void __launch_bounds__(256) k_policy_head(HeadArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int o = 4 * g4 + q;
-                l[q] = (o < a.A) ? out[q] + ((dec == 1.0f && o >= 5) ? -1e9f : 0.0f) : -INFINITY;
+                // agent_network.py:71-75: decision 1 -> mask_5 (actions 0..4), decision 0 -> all ones, anything else -> the
+                // all-zero mask (every logit + -1e9: a uniform distribution in float32)
+                const bool off = (dec == 1.0f) ? (o >= 5) : (dec != 0.0f);
+                l[q] = (o < a.A) ? out[q] + (off ? -1e9f : 0.0f) : -INFINITY;
                 mx = fmaxf(mx, l[q]);
             }
             mx = fmaxf(mx, xlane(mx, 16));

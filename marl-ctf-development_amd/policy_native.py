@@ -101,15 +101,32 @@ class CtfPolicyNative(CtfPolicy):
         super().__init__(n_actions, n_channels, grid_size, metadata_size, compute_dtype=torch.bfloat16)
         self.grid_size, self.metadata_size, self.n_channels = grid_size, metadata_size, n_channels
         self._prep = None
-        self._seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)  # Philox key of the action sampler
-        self._calls = 0                                                                    # ... and its running offset
+        # Philox key of the action sampler and its running offset.  The key is unique per INSTANCE: a default-constructed
+        # module draws it from torch's generator (reproducible under torch.manual_seed, different for every module built),
+        # and a copy / unpickled module draws a new one (__setstate__) — two networks that share (key, offset) would sample
+        # from identical uniforms, i.e. perfectly correlated exploration of agent and opponent in self-play.
+        self._seed = self._fresh_key() if seed is None else int(seed) & (2 ** 64 - 1)
+        self._calls = 0
         self._act_bufs = {}        # persistent activation matrices of act_from_codes, by (rows, row length, device)
         self.placement_probe_ms = None
+
+    @staticmethod
+    def _fresh_key():
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+    def reseed(self, seed):
+        """Set the action sampler's Philox key explicitly (and restart its offset)."""
+        self._seed, self._calls = int(seed) & (2 ** 64 - 1), 0
+        return self
 
     def __getstate__(self):  # copies / pickles carry the parameters, not the kernel-side operands or device buffers
         d = dict(self.__dict__)
         d["_prep"], d["_act_bufs"] = None, {}
         return d
+
+    def __setstate__(self, state):  # copy.deepcopy / pickle: the copy samples from its own stream (see __init__)
+        super().__setstate__(state)
+        self._seed, self._calls = self._fresh_key(), 0
 
     # -- weights in the kernels' / the GEMM's layouts ----------------------------------------------
     def prepare(self):

@@ -195,6 +195,44 @@ def test_fused_tail_samples_the_softmax():
         assert float((freq - probs).abs().max()) < 6e-3, (freq, probs)  # ~4 sigma at B = 131072
 
 
+def test_decision_values_other_than_0_or_1_give_the_references_all_zero_mask():
+    """agent_network.py:71-75: a decision that is neither 0 nor 1 leaves the all-zero mask, every logit gets -1e9 and the
+    float32 distribution is uniform."""
+    net = fill_(native.CtfPolicyNative(9, 14, 15, 22, seed=5)).cuda()
+    B = 4096
+    y1 = (torch.randn((B, 256), generator=torch.Generator().manual_seed(2)) * 0.7).to(torch.bfloat16).cuda()
+    mask = torch.full((B,), 2.0, device="cuda")
+    action, lp, ent, val, logits = net._head(y1, mask=mask, want_logits=True)
+    dist = torch.distributions.Categorical(logits=logits + (torch.zeros_like(logits) - 1.0) * 1e9)
+    assert torch.allclose(lp, dist.log_prob(action.long()), atol=1e-4) and torch.allclose(ent, dist.entropy(), atol=1e-4)
+    assert torch.allclose(ent, torch.full_like(ent, math.log(9.0)), atol=1e-4)
+    assert int(action.max()) > 4  # nothing is masked off
+
+
+def test_every_policy_instance_samples_from_its_own_stream():
+    """Two default-constructed networks, and a deepcopy / pickle of one, must not share (Philox key, offset): identical
+    uniforms for agent and opponent would correlate their exploration perfectly in self-play."""
+    import copy
+    import pickle
+
+    a = fill_(native.CtfPolicyNative(9, 14, 15, 22))
+    b = fill_(native.CtfPolicyNative(9, 14, 15, 22))
+    c = copy.deepcopy(a)
+    d = pickle.loads(pickle.dumps(a))
+    assert len({a._seed, b._seed, c._seed, d._seed}) == 4
+    B = 8192
+    y1 = torch.zeros((B, 256), dtype=torch.bfloat16, device="cuda")  # identical, flat logits for every sample
+    draws = [net.cuda()._head(y1)[0] for net in (a, b, c, d)]
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert float((draws[i] == draws[j]).float().mean()) < 0.5  # independent draws agree ~1/9 of the time
+    torch.manual_seed(123)
+    k1 = native.CtfPolicyNative(9, 14, 15, 22)._seed
+    torch.manual_seed(123)
+    assert native.CtfPolicyNative(9, 14, 15, 22)._seed == k1  # reproducible under torch.manual_seed
+    assert native.CtfPolicyNative(9, 14, 15, 22, seed=77).reseed(78)._seed == 78
+
+
 def test_full_size_batch_is_deterministic_and_matches_the_emulation_on_a_sample():
     """BASELINE size: 65 536 arena envs x 8 agents = 524 288 samples (a 4.1 GB activation matrix: 64-bit offsets)."""
     kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
@@ -232,6 +270,41 @@ def test_full_size_batch_is_deterministic_and_matches_the_emulation_on_a_sample(
     assert float((a1[0] == a2[0]).float().mean()) > 0.995
     assert torch.allclose(a1[3], a2[3], atol=2e-2) and torch.allclose(a1[2], a2[2], atol=2e-2)
     assert int(a1[0].min()) >= 0 and int(a1[0].max()) <= 8 and bool(torch.isfinite(a1[1]).all())
+    vec.close()
+
+
+def test_full_size_split_batch_is_deterministic_and_matches_the_emulation():
+    """G = 11 (0_the_split) at 65 536 envs x 4 agents: the NP = 2 instantiation of both front kernels, whose prefetch wait
+    once listed one register several times (the compiler then copied the load's destination before the wait: timing-
+    dependent activations that the small goldens never exposed).  Run-to-run identical, shared-view == per-agent, and a
+    sample spread over the whole batch equal to the float64 emulation."""
+    kw = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow)
+    E = 65536
+    vec = pkg.VecGridworldCtf(E, device=0, py_seeds=np.arange(E) + 11, np_seeds=np.arange(E) + 11, **kw)
+    n = vec.N_AGENTS
+    acts = torch.empty((E, n), dtype=torch.int8, device="cuda")
+    for t in range(9):
+        vec.random_actions(acts, seed=6, step=t)
+        vec.step(acts)
+    codes, meta = vec.observe_codes()
+    net = fill_(native.CtfPolicyNative(9, vec.N_CHANNELS, 11, vec.META_LEN, seed=3)).cuda()
+    sel = list(range(n))
+    f1 = net.features_from_codes(codes, meta, sel)
+    for _ in range(4):
+        assert torch.equal(net.features_from_codes(codes, meta, sel), f1)
+    real = torch.from_numpy(native.act_column_order(11, vec.META_LEN) >= 0).cuda()
+    for team in (0, 1):
+        team_agents = [i for i in range(n) if vec.AGENT_TEAMS[i] == team]
+        for _ in range(3):
+            ft = net.features_from_codes(codes, meta, team_agents, shared_view=True, self_cells=vec.self_cells)
+            for j, ag in enumerate(team_agents):
+                assert torch.equal(ft[j * E:(j + 1) * E][:, real], f1[ag * E:(ag + 1) * E][:, real]), (team, ag)
+    g = torch.Generator().manual_seed(0)
+    rows = torch.cat((torch.tensor([0, 1, E - 1, E, n * E - 1]), torch.randint(0, n * E, (251,), generator=g))).cuda()  # row k * E + e
+    k, e = (rows // E).cpu(), (rows % E).cpu()
+    planes = torch.tensor(pkg.expand_codes(codes.cpu().numpy()[e, k], vec.N_CHANNELS))
+    want = emulate(net, planes, meta.cpu()[e, k])
+    assert float((unpermute(net, f1[rows]) - want).abs().max()) <= 2.0 ** -7
     vec.close()
 
 
