@@ -199,6 +199,106 @@ def test_full_size_arena_properties_and_sample():
     vec.close()
 
 
+def _workload(name):
+    if name == "arena20":
+        return dict(pkg.configs.ARENA20_KWARGS, SCENARIO=pkg.configs.arena20_scenario())
+    return dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+
+
+@pytest.mark.parametrize("workload,auto_reset", [("arena", True), ("arena", False), ("arena20", True)])
+def test_bench_variant_at_bench_size_over_an_episode_end_and_a_visitation_fold(workload, auto_reset):
+    """The kernel variant bench.py times — metrics counters + visitation log ON, 65 536 envs — for 520 steps: with
+    auto_reset the episode ends at step 500 and every env is reset inside the step launch; without it the envs run past
+    GAME_STEPS and cross the 511-step in-kernel fold of the visitation log (gridworld_ctf.py:849-918, :479-486).  A 64-env
+    sample is stepped through the oracle beside the GPU and compared after EVERY step (rewards f64, done, all N
+    observations, all N metadata rows); at the end: every counter of ``counters()`` for the sample, the full state views
+    (visitation maps included) and both MT19937 states.  Size-independent properties hold on all 65 536 envs throughout."""
+    kw = _workload(workload)
+    E, steps = 65536, 520
+    seeds = np.arange(E, dtype=np.uint64) + 2_000_006
+    vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=True, **kw)
+    n, g = vec.N_AGENTS, vec.GRID_SIZE
+    cfg, _ = pkg.config.build_config(kw, log_metrics=True)
+    sample = np.unique(np.concatenate([np.linspace(0, E - 1, 61).astype(int), [1, 63, 64]]))
+    sidx = torch.from_numpy(sample).to(vec.device)
+    refs = [oracle.OracleEnv(cfg) for _ in sample]
+    for e, r in zip(sample, refs):
+        r.seed(int(seeds[e]), int(seeds[e]))
+    acts = torch.empty((E, n), dtype=torch.int8, device=vec.device)
+    tiles = vec.TILES_USED
+    own = [k + 1 for k, tl in enumerate(tiles) if 4 <= tl <= 7]
+    opp = [k + 1 for k, tl in enumerate(tiles) if 8 <= tl <= 11]
+    for t in range(steps):
+        vec.random_actions(acts, seed=0xBE7C, step=t)
+        rewards, done, obs, meta = vec.step_observe(acts, auto_reset=auto_reset, want_f64=True)
+        if t % 40 == 0 or t in (499, 500, 501, 510, 511, 512, steps - 1):  # properties of every env (1.65 / 2.9 GB reductions)
+            assert bool((obs[:, :, 0].sum(dim=(2, 3), dtype=torch.int32) == 1).all()) and int(obs.max()) == 1
+            assert bool((obs[:, :, own].sum(dim=(2, 3, 4), dtype=torch.int32) == 4).all())
+            assert bool((obs[:, :, opp].sum(dim=(2, 3, 4), dtype=torch.int32) == 4).all())
+            want_done = (t + 1 >= 500) if not auto_reset else (t + 1 == 500)
+            assert bool((done == int(want_done)).all()), t
+            codes, _ = vec.observe_codes(meta=False)
+            for lo in range(0, E, 16384):
+                assert torch.equal(pkg.expand_codes(codes[lo:lo + 16384], vec.N_CHANNELS), obs[lo:lo + 16384]), (t, lo)
+        a = acts[sidx].cpu().numpy()
+        o = obs[sidx].cpu().numpy()
+        m = meta[sidx].cpu().numpy().view(np.uint16)
+        r64 = vec.rewards64[sidx].cpu().numpy()
+        r32 = rewards[sidx].cpu().numpy()
+        d = done[sidx].cpu().numpy()
+        for k, r in enumerate(refs):
+            if auto_reset and r.get_state().done:
+                r.reset()
+            rw, dn, status = r.step(a[k])
+            assert status == 0
+            ro, rm = r.observe()
+            ctx = f"{workload} env {sample[k]} step {t}"
+            assert np.array_equal(r64[k], rw) and np.array_equal(r32[k], rw.astype(np.float32)), ctx
+            assert int(d[k]) == int(dn), ctx
+            assert np.array_equal(o[k], ro), ctx
+            assert np.array_equal(m[k], rm.view(np.uint16)), ctx
+    met, caps, nsteps = vec.counters()
+    met, caps, nsteps = met[sidx].cpu().numpy(), caps[sidx].cpu().numpy(), nsteps[sidx].cpu().numpy()
+    for k, r in enumerate(refs):
+        want = view_arrays(r.get_state(), n, g)
+        assert np.array_equal(met[k], want["metrics"]), f"{workload} env {sample[k]}: counters()"
+        assert list(caps[k]) == want["team_captures"] and int(nsteps[k]) == want["step_count"]
+        assert want["step_count"] == (steps if not auto_reset else steps - 500)
+        _state_equal(view_arrays(vec.get_state(int(sample[k])), n, g), want, f"{workload} env {sample[k]} final state")
+        py, npw = vec.get_rng_state(int(sample[k]))
+        rpy, rnp = r.get_rng_state()
+        assert np.array_equal(py, rpy) and np.array_equal(npw, rnp)
+    assert vec.status() == 0
+    vec.close()
+
+
+@pytest.mark.parametrize("workload", ["arena", "arena20", "split"])
+def test_full_size_renders_are_run_to_run_identical(workload):
+    """The render's next-env state arrives through hand-placed loads with counted waits (ctf_kernels.hip): a wait that is
+    one store short would show up as rare, timing-dependent differences at full size only.  Both renders, four runs each
+    into fresh buffers on a busy device, must be identical — and equal to each other through expand_codes."""
+    kw = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow) if workload == "split" else _workload(workload)
+    E = 65536
+    vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=np.arange(E) + 3, np_seeds=np.arange(E) + 3, **kw)
+    acts = torch.empty((E, vec.N_AGENTS), dtype=torch.int8, device=vec.device)
+    for t in range(25):
+        vec.random_actions(acts, seed=77, step=t)
+        vec.step(acts)
+    first_obs, first_meta = (x.clone() for x in vec.observe())
+    first_codes = vec.observe_codes()[0].clone()
+    for run in range(4):
+        vec.obs = torch.empty_like(first_obs)   # another placement each time
+        vec.meta.zero_()
+        obs, meta = vec.observe()
+        assert torch.equal(obs, first_obs) and torch.equal(meta, first_meta), run
+        vec.codes.zero_()
+        codes, meta = vec.observe_codes()
+        assert torch.equal(codes, first_codes) and torch.equal(meta, first_meta), run
+    for lo in range(0, E, 16384):
+        assert torch.equal(pkg.expand_codes(first_codes[lo:lo + 16384], vec.N_CHANNELS), first_obs[lo:lo + 16384])
+    vec.close()
+
+
 def test_reset_mask_and_state_roundtrip():
     case = Case("arena_random")
     vec = pkg.VecGridworldCtf(8, device=_dev(), **case.kwargs)

@@ -205,8 +205,9 @@ def test_decision_values_other_than_0_or_1_give_the_references_all_zero_mask():
     action, lp, ent, val, logits = net._head(y1, mask=mask, want_logits=True)
     dist = torch.distributions.Categorical(logits=logits + (torch.zeros_like(logits) - 1.0) * 1e9)
     assert torch.allclose(lp, dist.log_prob(action.long()), atol=1e-4) and torch.allclose(ent, dist.entropy(), atol=1e-4)
-    assert torch.allclose(ent, torch.full_like(ent, math.log(9.0)), atol=1e-4)
-    assert int(action.max()) > 4  # nothing is masked off
+    # (in float32 -1e9 + log 9 == -1e9: torch reports log-prob 0 and entropy 0 for this distribution, and so does the kernel)
+    freq = torch.bincount(action.long(), minlength=9).float() / B
+    assert float((freq - 1.0 / 9.0).abs().max()) < 0.03  # the draw itself is uniform: nothing is masked off
 
 
 def test_every_policy_instance_samples_from_its_own_stream():
