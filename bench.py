@@ -7,11 +7,22 @@
 
 One "step" = one pass of the hot path over one batch: GridworldCtf.step() for every env of the shard
 plus the N observations + metadata rows a rollout consumes (reference ppo.py:59-98), with auto-reset at
-episode end.  Workload at N=1: BASELINE.json configs[2] — 8_arena (arena_iii, 4v4, the reference's
-15x15 map), 65 536 envs resident in HBM; N>1 keeps 65 536 envs per GPU (weak scaling), envs sharded by
-global index with no data-path collective (--rollout-exchange adds an asynchronous RCCL all-gather of the
-compact rollout tensors once per 16-step chunk, what a centralised learner would need).  Inputs (Philox
-action streams for every timed step) are generated on the device before the timed region.
+episode end — one call of ctf_step_observe.  Workload at N=1: BASELINE.json configs[2] — 8_arena
+(arena_iii, 4v4, the reference's 15x15 map), 65 536 envs resident in HBM; N>1 keeps 65 536 envs per GPU
+(weak scaling), envs sharded by global index with no data-path collective (--rollout-exchange adds an
+asynchronous RCCL all-gather of the compact rollout tensors once per 16-step chunk, what a centralised
+learner would need).  Inputs (Philox action streams for every timed step) are generated on the device
+before the timed region.
+
+Protocol: before the timed region every env plays a first, discarded episode and the envs
+are put at STAGGERED episode phases (env e has env_step_count = 499 - e % 500), so that any timed window
+holds the steady-state mix: ~E/500 envs reach GAME_STEPS and are reset inside the launch at every step,
+agents are spread over the map, tags / respawns / flag events occur at their steady-state rates.  (The
+511-step visitation-log fold cannot occur under this protocol: an episode ends at 500 steps.)
+
+At N=1 the line also carries, as `secondary`, the other single-GPU BASELINE configurations run the same
+way — the synthetic 20x20 arena at 65 536 envs (BASELINE.json's wording) and 0_the_split at 4 096 envs
+(configs[1]) — each with its own roofline.
 
 Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for the roofline / cpu_baseline fields).
 """
@@ -41,6 +52,20 @@ def step_algorithmic_bytes(n, g):
     return 2 * g * g + 2 * 14 * n + (n + 4 * n + 1) + 8 * (n * n + 2 * n - 2)
 
 
+def env_step_algorithmic_bytes(n, c, g):
+    """SURVEY §8d's per-env-step total (26 891 B on 8_arena, 4 535 B on 0_the_split): what ONE fused step+observe
+    launch must move per env — the grid and agent state are read and written once, not re-read by the render."""
+    return n * c * g * g + n * (2 * n + 6) * 2 + step_algorithmic_bytes(n, g)
+
+
+WORKLOADS = {
+    "arena": ("8_arena (arena_iii 15x15, 4v4 heterogeneous)", lambda pkg: dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)),
+    "arena20": ("8_arena agents and rules on a synthetic 20x20 map (4v4 heterogeneous)",
+                lambda pkg: dict(pkg.configs.ARENA20_KWARGS, SCENARIO=pkg.configs.arena20_scenario())),
+    "split": ("0_the_split (arrow 11x11, 2v2)", lambda pkg: dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow)),
+}
+
+
 def cpu_baseline(pkg, kwargs, budget_s=12.0):
     """The CPU oracle (kind "port": the C restatement pinned to the reference by tests/golden) timed on this
     box's host cores on a bounded sample of the same workload: batches of arena envs x 200 steps of
@@ -60,13 +85,138 @@ def cpu_baseline(pkg, kwargs, budget_s=12.0):
         oracle.run_batch(cfg, batch, steps, 1_000_003 + done_envs, 7, True, cores)
         done_envs += batch
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": done_envs * steps / dt,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{done_envs} envs x {steps} steps, 8_arena step()+observe(), C oracle, OpenMP over envs ({dt:.1f} s)",
         "single_core_value": one,
+    }
+    try:  # the per-env Python/NumPy restatement on one core: calibrates this box against BASELINE.md's 1.2 k env-steps/s
+        from oracle import ctf_numpy
+
+        out["python_numpy_1core"] = ctf_numpy.timed_sample(kwargs, budget_s=6.0)
+    except ImportError:
+        pass
+    return out
+
+
+def stagger_phases(vec, torch, lo, period=500):
+    """A first (discarded) episode for every env, leaving env e at env_step_count = period - 1 - e % period."""
+    E, N = vec.n_envs, vec.N_AGENTS
+    acts = torch.empty((E, N), dtype=torch.int8, device=vec.device)
+    phase = torch.arange(E, device=vec.device) % period
+    for s in range(period):
+        vec.random_actions(acts, seed=0x5747, step=s, env_offset=lo)
+        vec.step(acts, auto_reset=True)
+        vec.reset((phase == s).to(torch.uint8))
+    torch.cuda.synchronize()
+
+
+def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_metrics=True, stagger=True, gather=None, dist=None,
+                 extras=True):
+    """-> dict of this rank's measurements of one workload (timed region = K calls of step_observe)."""
+    sh = pkg.sharding
+    label, make_kwargs = WORKLOADS[name]
+    kwargs = make_kwargs(pkg)
+    device = torch.device("cuda", local_rank)
+    lo = rank * E
+    seeds = sh.env_seeds(run, lo, lo + E)
+    vec = pkg.VecGridworldCtf(E, device=local_rank, py_seeds=seeds, np_seeds=seeds, log_metrics=log_metrics, **kwargs)
+    N, G, C = vec.N_AGENTS, vec.GRID_SIZE, vec.N_CHANNELS
+    actions = torch.empty((W + K, E, N), dtype=torch.int8, device=device)
+    for t in range(W + K):
+        vec.random_actions(actions[t], seed=0xC7F, step=t, env_offset=lo)
+    vec.observe()  # allocates (and places) the observation buffer
+    if stagger:
+        stagger_phases(vec, torch, lo, kwargs["GAME_STEPS"])
+    launches = vec.step_observe_launches()
+
+    def one_step(t, events=None):
+        if gather is not None:
+            vec.rewards, vec.done = gather.views(t)
+        if events:
+            events[0].record()
+        vec.step_observe(actions[t], auto_reset=True)
+        if events:
+            events[1].record()
+        if gather is not None:
+            gather.step_done(t)  # closes a chunk every 16th step: issued after the launch, it runs beside the next one
+
+    for t in range(W):
+        one_step(t)
+    if gather is not None:
+        gather.wait()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(K):
+        one_step(W + t, ev[t])
+    if gather is not None:
+        gather.flush(W + K)
+        gather.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    status = vec.status()
+    import numpy as np
+
+    call_all = np.array([e[0].elapsed_time(e[1]) for e in ev])
+    out = dict(name=name, label=label, E=E, N=N, G=G, C=C, K=K, W=W, elapsed=elapsed, launches=launches, status=status,
+               call_ms=float(call_all.mean()), call_ms_p10_p50_p90=[float(x) for x in np.percentile(call_all, [10, 50, 90])],
+               placement_probe_ms=vec.placement_probe_ms, kwargs=kwargs)
+    if extras:
+        # outside the timed region: the two launches of ctf_step + ctf_observe timed separately (their own HIP events), and
+        # the same env-step with the observation in compact form (ctf_observe_codes: what the GPU policy path consumes)
+        ev3 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+        for t in range(K):
+            ev3[t][0].record()
+            vec.step(actions[W + t], auto_reset=True)
+            ev3[t][1].record()
+            vec.observe()
+            ev3[t][2].record()
+        torch.cuda.synchronize()
+        out["k_step_ms"] = float(np.mean([e[0].elapsed_time(e[1]) for e in ev3]))
+        out["k_observe_ms"] = float(np.mean([e[1].elapsed_time(e[2]) for e in ev3]))
+        tc = time.perf_counter()
+        for t in range(K):
+            vec.step(actions[W + t], auto_reset=True)
+            vec.observe_codes()
+        torch.cuda.synchronize()
+        out["compact_rate"] = E * K / (time.perf_counter() - tc)
+        _, _, nsteps = vec.counters()
+        out["episode_phase_spread"] = [int(nsteps.min()), int(nsteps.max())]
+    vec.close()
+    del vec, actions
+    torch.cuda.empty_cache()
+    return out
+
+
+def roofline_of(r, traffic_table):
+    """roofline object of the dominant kernel of one workload's run."""
+    N, G, C, E = r["N"], r["G"], r["C"], r["E"]
+    if r["launches"] == 1:
+        kernel, per_env, ms = "k_step_observe", env_step_algorithmic_bytes(N, C, G), r["call_ms"]
+    else:
+        kernel, per_env, ms = "k_observe", observe_algorithmic_bytes(N, C, G), r.get("k_observe_ms", r["call_ms"])
+    achieved = per_env * E / (ms * 1e-3) / 1e9
+    entry = traffic_table.get(f"{r['name']}_{E}", {})
+    return {
+        "bound": "hbm",
+        "kernel": kernel,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": entry.get(f"{kernel}_hbm_bytes_per_launch"),
+        "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of " + entry.get("source", "?") +
+                           ", not measured in this run)") if entry.get(f"{kernel}_hbm_bytes_per_launch") else None,
+        "algorithmic_bytes_per_env": per_env,
+        "avg_launch_ms": ms,
     }
 
 
@@ -76,11 +226,13 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
-    ap.add_argument("--workload", choices=["arena", "split", "arena20"], default="arena",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="arena",
                     help="arena: 8_arena on the reference's 15x15 arena_iii (the headline); split: 0_the_split, use with "
                          "--envs-per-gpu 4096; arena20: the 8_arena agents and rules on a synthetic 20x20 map")
     ap.add_argument("--no-metrics", action="store_true", help="compile the reference's metric counters out of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the arena20 / split secondaries of the N=1 line")
+    ap.add_argument("--no-stagger", action="store_true", help="start the timed region at episode step 0 with all envs in lock-step")
     ap.add_argument("--rollout-exchange", action="store_true",
                     help="also all-gather the compact rollout tensors (rewards, done) over RCCL, once per 16-step chunk, for a "
                          "centralised learner; off by default: env shards are independent and a data-parallel learner needs no exchange")
@@ -93,7 +245,6 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
     import torch
 
     pkg = importlib.import_module("marl-ctf-development_amd")
@@ -105,92 +256,36 @@ def main():
     device = torch.device("cuda", local_rank)
     # CTF_FORCE_DIST=1 runs the RCCL code path even with one rank (rehearsal of the N>1 path on a 1-GPU box)
     use_dist = world > 1 or bool(os.environ.get("CTF_FORCE_DIST"))
+    dist = None
     if use_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=device)
     n_gpus = world
+    E, K, W = args.envs_per_gpu, args.steps, args.warmup
 
-    if args.workload == "arena":
-        kwargs = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
-        label = "8_arena (arena_iii 15x15, 4v4 heterogeneous)"
-    elif args.workload == "arena20":
-        kwargs = dict(pkg.configs.ARENA20_KWARGS, SCENARIO=pkg.configs.arena20_scenario())
-        label = "8_arena agents and rules on a synthetic 20x20 map (4v4 heterogeneous)"
-    else:
-        kwargs = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow)
-        label = "0_the_split (arrow 11x11, 2v2)"
-    E = args.envs_per_gpu
-    lo = rank * E
-    seeds = sh.env_seeds(args.run, lo, lo + E)
-    vec = pkg.VecGridworldCtf(E, device=local_rank, py_seeds=seeds, np_seeds=seeds, log_metrics=not args.no_metrics, **kwargs)
-    N, G, C = vec.N_AGENTS, vec.GRID_SIZE, vec.N_CHANNELS
-
-    K, W = args.steps, args.warmup
-    actions = torch.empty((W + K, E, N), dtype=torch.int8, device=device)
-    for t in range(W + K):
-        vec.random_actions(actions[t], seed=0xC7F, step=t, env_offset=lo)
     # The path shards with NO data-path collective: envs are independent, every rank steps and renders its own shard, and a
     # data-parallel learner consumes the observations where they are.  --rollout-exchange adds the hand-off a centralised
     # learner would need: the step kernel writes rewards / done straight into a chunk buffer that is all-gathered (RCCL,
-    # async) once per 16 steps.  Measured at one rank it costs 13 %: the collective's blocks take wave slots on a few CUs
-    # and the render, which fills every slot with equal shares of work, waits for its displaced blocks.
+    # async) once per 16 steps.
     exchange = use_dist and args.rollout_exchange
-    gather = sh.ChunkedRolloutGather(E, N, device, world, chunk=16, force_collective=exchange)
-    vec.observe()
-
-    def one_step(t, events=None):
-        vec.rewards, vec.done = gather.views(t)
-        if events:
-            events[0].record()
-        vec.step(actions[t], auto_reset=True)
-        if events:
-            events[1].record()
-        vec.observe()
-        if events:
-            events[2].record()
-        gather.step_done(t)  # closes a chunk every 16th step: issued after the render, it runs beside the next step kernel
-
-    for t in range(W):
-        one_step(t)
-    gather.wait()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    n_agents = len(WORKLOADS[args.workload][1](pkg)["AGENT_CONFIG"])
+    gather = sh.ChunkedRolloutGather(E, n_agents, device, world, chunk=16, force_collective=exchange) if exchange else None
+    r = run_workload(pkg, torch, args.workload, E, K, W, rank, local_rank, world, args.run, log_metrics=not args.no_metrics,
+                     stagger=not args.no_stagger, gather=gather, dist=dist, extras=(rank == 0))
+    my_ms = r["elapsed"] / K * 1e3
+    elapsed = sh.max_over_ranks(r["elapsed"], device, world if not use_dist else max(world, 2))
+    ranks_seen, per_rank_ms = [rank], [my_ms]
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(K):
-        one_step(W + t, ev[t])
-    gather.flush(W + K)
-    gather.wait()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sh.max_over_ranks(elapsed, device, world if not use_dist else max(world, 2))
-    status = vec.status()
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, (rank, my_ms))
+        ranks_seen, per_rank_ms = [g[0] for g in got], [g[1] for g in got]
 
-    # secondary figure, outside the timed region: the same env-step with the observation in compact form
-    # (ctf_observe_codes: one byte per cell instead of C one-hot bytes — what the GPU policy path consumes)
-    torch.cuda.synchronize()
-    tc = time.perf_counter()
-    for t in range(K):
-        vec.step(actions[W + t], auto_reset=True)
-        vec.observe_codes()
-    torch.cuda.synchronize()
-    compact_rate = E * K / (time.perf_counter() - tc)
-
-    step_all = np.array([e[0].elapsed_time(e[1]) for e in ev])
-    obs_all = np.array([e[1].elapsed_time(e[2]) for e in ev])
-    step_ms, obs_ms = float(step_all.mean()), float(obs_all.mean())
     if rank == 0:
-        value = n_gpus * E * K / elapsed
-        obs_bytes = observe_algorithmic_bytes(N, C, G) * E
-        achieved = obs_bytes / (obs_ms * 1e-3) / 1e9
-        traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{args.workload}_{E}", {}).get("k_observe_hbm_bytes_per_launch")
+        traffic_table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        N, G, C = r["N"], r["G"], r["C"]
+        value = n_gpus * E * K / elapsed
         line = {
             "metric": "env-steps/sec",
             "value": value,
@@ -205,38 +300,50 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{label}, {E} envs/GPU resident in HBM, step()+observe() per env-step "
-                            f"(u8 obs [N={N}][C={C}][{G}][{G}], f16 metadata), Philox uniform actions, auto-reset at GAME_STEPS=500",
+                "workload": f"{r['label']}, {E} envs/GPU resident in HBM, step()+observe() per env-step "
+                            f"(u8 obs [N={N}][C={C}][{G}][{G}], f16 metadata), Philox uniform actions, auto-reset at GAME_STEPS=500, "
+                            + ("envs at staggered episode phases after a discarded first episode" if not args.no_stagger
+                               else "all envs in lock-step from episode step 0"),
                 "envs_per_gpu": E,
                 "global_envs": n_gpus * E,
                 "metrics_counters": not args.no_metrics,
+                "launches_per_step": r["launches"],
                 "rollout_exchange": ("RCCL all-gather of rewards+done per 16-step chunk, async" if exchange else
                                      "none: env shards are independent (data-parallel learner)"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_observe",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_env": observe_algorithmic_bytes(N, C, G),
-                "avg_launch_ms": obs_ms,
-            },
-            "kernels_ms": {"k_step": step_ms, "k_observe": obs_ms},
-            "kernels_ms_p10_p50_p90": {"k_step": [float(x) for x in np.percentile(step_all, [10, 50, 90])],
-                                       "k_observe": [float(x) for x in np.percentile(obs_all, [10, 50, 90])]},
-            "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (step_ms * 1e-3) / 1e9,
-            "device_status_bits": status,
-            "compact_observation": {"env_steps_per_s_per_gpu": compact_rate, "obs_bytes_per_env": N * G * G + N * (2 * N + 6) * 2,
+            "roofline": roofline_of(r, traffic_table),
+            "whole_step_hbm_frac": env_step_algorithmic_bytes(N, C, G) * value / n_gpus / 1e9 / HBM_PEAK_GBS,
+            "call_ms": r["call_ms"],
+            "call_ms_p10_p50_p90": r["call_ms_p10_p50_p90"],
+            "separate_launches_ms": {"k_step": r.get("k_step_ms"), "k_observe": r.get("k_observe_ms"),
+                                     "note": "ctf_step and ctf_observe as two launches, timed outside the timed region"},
+            "episode_phase_spread": r.get("episode_phase_spread"),
+            "placement_probe_ms": r["placement_probe_ms"],
+            "device_status_bits": r["status"],
+            "ranks_seen": sorted(ranks_seen),
+            "per_rank_ms_per_step": [per_rank_ms[ranks_seen.index(k)] for k in sorted(ranks_seen)],
+            "compact_observation": {"env_steps_per_s_per_gpu": r.get("compact_rate"), "obs_bytes_per_env": N * G * G + N * (2 * N + 6) * 2,
                                     "note": "step() + observe_codes(); not the headline metric (the reference's consumers take the one-hot planes)"},
         }
+        if n_gpus == 1 and not args.no_secondary and args.workload == "arena":
+            sec = {}
+            for name, e2 in (("arena20", 65536), ("split", 4096)):
+                k2 = max(20, min(K, 100))
+                r2 = run_workload(pkg, torch, name, e2, k2, W, 0, local_rank, 1, args.run, log_metrics=not args.no_metrics,
+                                  stagger=not args.no_stagger)
+                v2 = e2 * k2 / r2["elapsed"]
+                sec[f"{name}_{e2}"] = {
+                    "workload": f"{r2['label']}, {e2} envs", "value": v2, "unit": "env-steps/s", "steps": k2, "ms_per_step": r2["elapsed"] / k2 * 1e3,
+                    "launches_per_step": r2["launches"], "roofline": roofline_of(r2, traffic_table),
+                    "whole_step_hbm_frac": env_step_algorithmic_bytes(r2["N"], r2["C"], r2["G"]) * v2 / 1e9 / HBM_PEAK_GBS,
+                    "separate_launches_ms": {"k_step": r2.get("k_step_ms"), "k_observe": r2.get("k_observe_ms")},
+                    "placement_probe_ms": r2["placement_probe_ms"], "device_status_bits": r2["status"],
+                }
+            line["secondary"] = sec
         if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pkg, kwargs)
+            line["cpu_baseline"] = cpu_baseline(pkg, r["kwargs"])
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    vec.close()
     if use_dist:
         dist.destroy_process_group()
 

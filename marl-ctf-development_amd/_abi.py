@@ -118,6 +118,7 @@ SYMBOLS = {
     "ctf_observe": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
     "ctf_observe_codes": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_step_observe": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P]),
+    "ctf_step_observe_launches": (C.c_int, [_P, _P]),
     "ctf_action_mask": (C.c_int, [_P, _P]),
     "ctf_get_state": (C.c_int, [_P, C.c_int32, C.POINTER(CtfStateView)]),
     "ctf_set_state": (C.c_int, [_P, C.c_int32, C.POINTER(CtfStateView)]),
@@ -163,8 +164,9 @@ def load_library(path=None):
     return lib
 
 
-def bind(path, mode=C.RTLD_GLOBAL):
-    """dlopen one build of the library and type its entry points (tools/ab_inproc.py loads several side by side)."""
+def bind(path, mode=C.RTLD_GLOBAL, optional=()):
+    """dlopen one build of the library and type its entry points (tools/ab_inproc.py loads several side by side; only that
+    tool passes ``optional``: name prefixes a partial or older build may lack)."""
     try:
         lib = C.CDLL(path, mode=mode)
     except OSError as exc:
@@ -173,6 +175,8 @@ def bind(path, mode=C.RTLD_GLOBAL):
         try:
             fn = getattr(lib, name)
         except AttributeError as exc:
+            if any(name.startswith(o) for o in optional):
+                continue
             raise CtfLibraryError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes

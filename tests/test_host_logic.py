@@ -145,7 +145,8 @@ def test_native_policy_module_copies_and_pickles_without_its_device_side_state()
     net._prep = {"lib": object(), "stamp": None}      # stands for the ctypes handle and device operands
     net._act_bufs = {(1, 2, 0): torch.zeros(1)}
     for clone in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
-        assert clone._prep is None and clone._act_bufs == {} and clone._seed == 5
+        assert clone._prep is None and clone._act_bufs == {}
+        assert clone._seed != 5 and clone._calls == 0  # a copy samples from its own Philox stream (policy_native.__setstate__)
         assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), net.state_dict().values()))
 
 

@@ -73,9 +73,16 @@ def test_lint_accepts_a_wait_in_the_issuing_iteration_and_sees_register_ranges(t
     assert [b[3] for b in isa_lint.lint_file(bad)[1]] == [[6, 7]]
 
 
-@pytest.mark.parametrize("target,listing", [("asm", "ctf_kernels.s"), ("asm-policy", "ctf_policy.s")])
-def test_shipped_kernels_keep_their_prefetch_registers_untouched(target, listing):
+@pytest.mark.parametrize("target,listing,uses_idiom", [("asm", "ctf_kernels.s", False), ("asm-policy", "ctf_policy.s", True)])
+def test_shipped_kernels_keep_their_prefetch_registers_untouched(target, listing, uses_idiom):
+    """ctf_policy.hip uses the idiom (both front kernels, G = 11 and 15).  The env kernels no longer do — since round 2 the
+    render pipelines build and stream inside a wave and its state loads are ordinary, compiler-tracked loads — but the
+    listing stays under the lint so that a future hand-placed load there is checked from its first build."""
     subprocess.check_call(["make", "-C", CSRC, "-s", target], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     summary, bad = isa_lint.lint_file(os.path.join(CSRC, listing))
-    assert summary, "no hand-placed loads found: the listing or the parser changed"
+    if uses_idiom:
+        assert summary, "no hand-placed loads found: the listing or the parser changed"
+        assert any("k_policy_featuresILi11E" in k for k in summary) and any("k_policy_features_teamILi11E" in k for k in summary)
     assert bad == [], "\n".join(f"{k}:{l}: `{t}` touches in-flight v{r}" for k, l, t, r in bad)
+    n_kernels = len(isa_lint.parse_functions(os.path.join(CSRC, listing)))
+    assert n_kernels >= 6, "the listing was not parsed into its kernels"

@@ -25,11 +25,16 @@ for i, flags in enumerate(sys.argv[1:]):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic",
                            "-I" + os.path.join(ROOT, "marl-ctf-development_amd", "csrc")]
                           + flags_only.split() + ["-shared", "-o", so, os.path.join(src, "ctf_abi.hip"), os.path.join(src, "ctf_kernels.hip")])
-    vecs.append((flags, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL), **kw)))
+    vecs.append((flags, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_", "ctf_step_observe_launches")), **kw)))
 shared_obs, shared_meta = vecs[0][1].obs, vecs[0][1].meta
 acts = torch.zeros((E, 8), dtype=torch.int8, device="cuda")
 vecs[0][1].random_actions(acts, seed=5, step=0)
-res = {f: ([], []) for f, _ in vecs}
+for t in range(int(os.environ.get("AB_PRESTEP", 0))):  # spread the agents over the map before timing anything
+    for flags, v in vecs:
+        v.random_actions(acts, seed=5, step=t)
+        v.step(acts, auto_reset=True)
+res = {f: ([], [], []) for f, _ in vecs}
+os.environ["CTF_FUSED"] = os.environ.get("AB_FUSED", "1")  # step_observe below: the single launch where the build has one
 for rnd in range(4):
     for flags, v in vecs:
         v.obs, v.meta = shared_obs, shared_meta
@@ -38,14 +43,19 @@ for rnd in range(4):
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(60)]
         for a, b, c in ev:
             a.record(); v.step(acts, auto_reset=True); b.record(); v.observe(); c.record()
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(60)]
+        for a, b in ev2:
+            a.record(); v.step_observe(acts, auto_reset=True); b.record()
         torch.cuda.synchronize()
         if rnd:
             res[flags][0].append(np.median([a.elapsed_time(b) for a, b, c in ev]))
             res[flags][1].append(np.median([b.elapsed_time(c) for a, b, c in ev]))
+            res[flags][2].append(np.median([a.elapsed_time(b) for a, b in ev2]))
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
 for a, b in ev:
     a.record(); shared_obs.fill_(1); b.record()
 torch.cuda.synchronize()
 print("reference: torch fill_ of the same buffer %.4f ms" % np.median([a.elapsed_time(b) for a, b in ev]), flush=True)
-for flags, (st, ob) in res.items():
-    print(f"[{flags or 'default'}] step {np.mean(st):.4f} ms  observe {np.mean(ob):.4f} ms  (rounds: {', '.join('%.4f' % x for x in ob)})", flush=True)
+for flags, (st, ob, so) in res.items():
+    print(f"[{flags or 'default'}] step {np.mean(st):.4f} ms  observe {np.mean(ob):.4f} ms  step_observe {np.mean(so):.4f} ms  "
+          f"(observe rounds: {', '.join('%.4f' % x for x in ob)})", flush=True)
