@@ -7,7 +7,8 @@
 
 One "step" = one pass of the hot path over one batch: GridworldCtf.step() for every env of the shard
 plus the N observations + metadata rows a rollout consumes (reference ppo.py:59-98), with auto-reset at
-episode end — one call of ctf_step_observe.  Workload at N=1: BASELINE.json configs[2] — 8_arena
+episode end — the two launches of ctf_step_observe (issued here as ctf_step + ctf_observe so that a HIP event
+can sit between them).  Workload at N=1: BASELINE.json configs[2] — 8_arena
 (arena_iii, 4v4, the reference's 15x15 map), 65 536 envs resident in HBM; N>1 keeps 65 536 envs per GPU
 (weak scaling), envs sharded by global index with no data-path collective (--rollout-exchange adds an
 asynchronous RCCL all-gather of the compact rollout tensors once per 16-step chunk, what a centralised
@@ -53,8 +54,8 @@ def step_algorithmic_bytes(n, g):
 
 
 def env_step_algorithmic_bytes(n, c, g):
-    """SURVEY §8d's per-env-step total (26 891 B on 8_arena, 4 535 B on 0_the_split): what ONE fused step+observe
-    launch must move per env — the grid and agent state are read and written once, not re-read by the render."""
+    """SURVEY §8d's per-env-step total (26 891 B on 8_arena, 4 535 B on 0_the_split): grid and agent state counted once
+    (the render's re-read of them is overhead, not algorithm)."""
     return n * c * g * g + n * (2 * n + 6) * 2 + step_algorithmic_bytes(n, g)
 
 
@@ -131,24 +132,27 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     vec.observe()  # allocates (and places) the observation buffer
     if stagger:
         stagger_phases(vec, torch, lo, kwargs["GAME_STEPS"])
-    launches = vec.step_observe_launches()
+    observe_kernel = "k_observe"
 
     def one_step(t, events=None):
         if gather is not None:
             vec.rewards, vec.done = gather.views(t)
         if events:
             events[0].record()
-        vec.step_observe(actions[t], auto_reset=True)
+        vec.step(actions[t], auto_reset=True)
         if events:
             events[1].record()
+        vec.observe()
+        if events:
+            events[2].record()
         if gather is not None:
-            gather.step_done(t)  # closes a chunk every 16th step: issued after the launch, it runs beside the next one
+            gather.step_done(t)  # closes a chunk every 16th step: issued after the render, it runs beside the next step kernel
 
     for t in range(W):
         one_step(t)
     if gather is not None:
         gather.wait()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,23 +169,17 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     status = vec.status()
     import numpy as np
 
-    call_all = np.array([e[0].elapsed_time(e[1]) for e in ev])
-    out = dict(name=name, label=label, E=E, N=N, G=G, C=C, K=K, W=W, elapsed=elapsed, launches=launches, status=status,
-               call_ms=float(call_all.mean()), call_ms_p10_p50_p90=[float(x) for x in np.percentile(call_all, [10, 50, 90])],
+    step_all = np.array([e[0].elapsed_time(e[1]) for e in ev])
+    obs_all = np.array([e[1].elapsed_time(e[2]) for e in ev])
+    out = dict(name=name, label=label, E=E, N=N, G=G, C=C, K=K, W=W, elapsed=elapsed, status=status, observe_kernel=observe_kernel,
+               k_step_ms=float(step_all.mean()), k_observe_ms=float(obs_all.mean()),
+               k_step_p=[float(x) for x in np.percentile(step_all, [10, 50, 90])],
+               k_observe_p=[float(x) for x in np.percentile(obs_all, [10, 50, 90])],
                placement_probe_ms=vec.placement_probe_ms, kwargs=kwargs)
     if extras:
-        # outside the timed region: the two launches of ctf_step + ctf_observe timed separately (their own HIP events), and
-        # the same env-step with the observation in compact form (ctf_observe_codes: what the GPU policy path consumes)
-        ev3 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
-        for t in range(K):
-            ev3[t][0].record()
-            vec.step(actions[W + t], auto_reset=True)
-            ev3[t][1].record()
-            vec.observe()
-            ev3[t][2].record()
+        # outside the timed region: the same env-step with the observation in compact form (ctf_observe_codes: one byte per
+        # cell instead of C one-hot bytes — what the GPU policy path consumes)
         torch.cuda.synchronize()
-        out["k_step_ms"] = float(np.mean([e[0].elapsed_time(e[1]) for e in ev3]))
-        out["k_observe_ms"] = float(np.mean([e[1].elapsed_time(e[2]) for e in ev3]))
         tc = time.perf_counter()
         for t in range(K):
             vec.step(actions[W + t], auto_reset=True)
@@ -199,10 +197,7 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
 def roofline_of(r, traffic_table):
     """roofline object of the dominant kernel of one workload's run."""
     N, G, C, E = r["N"], r["G"], r["C"], r["E"]
-    if r["launches"] == 1:
-        kernel, per_env, ms = "k_step_observe", env_step_algorithmic_bytes(N, C, G), r["call_ms"]
-    else:
-        kernel, per_env, ms = "k_observe", observe_algorithmic_bytes(N, C, G), r.get("k_observe_ms", r["call_ms"])
+    kernel, per_env, ms = r["observe_kernel"], observe_algorithmic_bytes(N, C, G), r["k_observe_ms"]
     achieved = per_env * E / (ms * 1e-3) / 1e9
     entry = traffic_table.get(f"{r['name']}_{E}", {})
     return {
@@ -307,16 +302,14 @@ def main():
                 "envs_per_gpu": E,
                 "global_envs": n_gpus * E,
                 "metrics_counters": not args.no_metrics,
-                "launches_per_step": r["launches"],
                 "rollout_exchange": ("RCCL all-gather of rewards+done per 16-step chunk, async" if exchange else
                                      "none: env shards are independent (data-parallel learner)"),
             },
             "roofline": roofline_of(r, traffic_table),
             "whole_step_hbm_frac": env_step_algorithmic_bytes(N, C, G) * value / n_gpus / 1e9 / HBM_PEAK_GBS,
-            "call_ms": r["call_ms"],
-            "call_ms_p10_p50_p90": r["call_ms_p10_p50_p90"],
-            "separate_launches_ms": {"k_step": r.get("k_step_ms"), "k_observe": r.get("k_observe_ms"),
-                                     "note": "ctf_step and ctf_observe as two launches, timed outside the timed region"},
+            "kernels_ms": {"k_step": r["k_step_ms"], r["observe_kernel"]: r["k_observe_ms"]},
+            "kernels_ms_p10_p50_p90": {"k_step": r["k_step_p"], r["observe_kernel"]: r["k_observe_p"]},
+            "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (r["k_step_ms"] * 1e-3) / 1e9,
             "episode_phase_spread": r.get("episode_phase_spread"),
             "placement_probe_ms": r["placement_probe_ms"],
             "device_status_bits": r["status"],
@@ -334,9 +327,9 @@ def main():
                 v2 = e2 * k2 / r2["elapsed"]
                 sec[f"{name}_{e2}"] = {
                     "workload": f"{r2['label']}, {e2} envs", "value": v2, "unit": "env-steps/s", "steps": k2, "ms_per_step": r2["elapsed"] / k2 * 1e3,
-                    "launches_per_step": r2["launches"], "roofline": roofline_of(r2, traffic_table),
+                    "roofline": roofline_of(r2, traffic_table),
                     "whole_step_hbm_frac": env_step_algorithmic_bytes(r2["N"], r2["C"], r2["G"]) * v2 / 1e9 / HBM_PEAK_GBS,
-                    "separate_launches_ms": {"k_step": r2.get("k_step_ms"), "k_observe": r2.get("k_observe_ms")},
+                    "kernels_ms": {"k_step": r2["k_step_ms"], r2["observe_kernel"]: r2["k_observe_ms"]},
                     "placement_probe_ms": r2["placement_probe_ms"], "device_status_bits": r2["status"],
                 }
             line["secondary"] = sec

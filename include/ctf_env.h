@@ -183,15 +183,13 @@ int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t rev
 int ctf_observe_codes(ctf_env* env, uint8_t* codes_dev, uint16_t* meta_dev, uint16_t* selfcell_dev, uint32_t reverse_mask,
                       void* stream);
 
-/* ctf_step immediately followed by ctf_observe (the rollout inner loop, ppo.py:59-98).  ONE launch (k_step_observe: every
- * wave steps a group of envs in LDS and renders those same envs from LDS, no second launch and no re-read of the state)
- * when obs_dev is given, the observation block is 16-byte aligned and the batch is large enough to give every resident
- * wave a group; otherwise the two launches of ctf_step + ctf_observe.  Results are identical either way. */
+/* ctf_step immediately followed by ctf_observe (the rollout inner loop, ppo.py:59-98): the two launches enqueued by one
+ * call.  (A single fused launch was built and measured in round 2 — bit-exact but 25 % slower, because a group's step
+ * is an ~85 us dependent chain that only the step kernel's "every group in flight at once" shape hides:
+ * profiles/r02_fused_step_observe_ablation.md.) */
 int ctf_step_observe(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev,
                      double* rewards_f64_dev, uint8_t* done_dev, uint8_t* obs_dev, uint16_t* meta_dev,
                      uint32_t reverse_mask, uint32_t flags, void* stream);
-/* How many kernel launches ctf_step_observe issues for this handle and observation buffer: 1 (fused) or 2. */
-int ctf_step_observe_launches(ctf_env* env, const uint8_t* obs_dev);
 
 /* AGENT_TYPE_ACTION_MASK expanded as agent_network.py:66-75 does: mask_host[i][a] = 1 if action a is
  * legal for agent i (flag 1 => actions 0..4 only).  Host buffer uint8 [N][9]. */

@@ -118,7 +118,6 @@ SYMBOLS = {
     "ctf_observe": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
     "ctf_observe_codes": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_step_observe": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P]),
-    "ctf_step_observe_launches": (C.c_int, [_P, _P]),
     "ctf_action_mask": (C.c_int, [_P, _P]),
     "ctf_get_state": (C.c_int, [_P, C.c_int32, C.POINTER(CtfStateView)]),
     "ctf_set_state": (C.c_int, [_P, C.c_int32, C.POINTER(CtfStateView)]),

@@ -18,8 +18,6 @@ extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint6
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
 extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
-extern "C" hipError_t ctf_launch_step_observe(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint8_t*,
-                                              uint16_t*, uint32_t, int, hipStream_t, int*);
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
@@ -373,22 +371,10 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
                                 uint16_t* meta, uint32_t reverse_mask, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    int fused = 0;
-    HIP_TRY(ctf_launch_step_observe(h->d, h->p, actions, rw32, rw64, done, flags, obs, meta, resolve_reverse(h, reverse_mask),
-                                    h->n_cus, (hipStream_t)stream, &fused));
-    if (fused) return CTF_OK;
     HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, (hipStream_t)stream));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;
-}
-
-extern "C" int ctf_step_observe_launches(ctf_env* h, const uint8_t* obs) {
-    if (!h) return fail(CTF_E_INVALID, "null handle");
-    DeviceGuard guard(h->device);
-    int fused = -1;  // plan only
-    HIP_TRY(ctf_launch_step_observe(h->d, h->p, nullptr, nullptr, nullptr, nullptr, 0, (uint8_t*)obs, nullptr, 0, h->n_cus, nullptr, &fused));
-    return fused ? 1 : 2;
 }
 
 extern "C" int ctf_action_mask(const ctf_env* h, uint8_t* mask_host) {

@@ -767,29 +767,18 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
 //      instruction per 64 chunks.
 // Metadata rows (f16 [N][2N+6]) are assembled in LDS and leave as 8-byte stores.
 //
-// Steps 1-2 (+ the metadata) of env k+1 are INTERLEAVED with step 3 of env k (two bitmaps per wave): every wave of
-// the launch starts at the same moment and every env costs the same, so with build and stream as separate phases all
-// waves build together and all stream together — the memory system idled through every build phase (43 of 305 us in
-// round 1's kernel, although a bare bitmap -> expand -> store stream runs within 1 % of constant-data stores:
-// tools/store_bw7.hip).  Interleaved, a wave's store stream never stops.
-//
-// Per-wave LDS (bytes): [rec RS][mvals 96][meta staging][meta source LUT][bitmap 0][bitmap 1]
+// Per-wave LDS (bytes): [rec RS][mvals 96][meta staging][meta source LUT][bitmap]
 #define OBS_MV_BYTES 96
 __host__ __device__ inline int obs_meta_stage_bytes(int N, int M) { return (N * M * 2 + 15) & ~15; }
 __host__ __device__ inline int obs_bitmap_bytes(int obs_bytes) { return ((((obs_bytes + 31) / 32 + 1) * 4) + 15) & ~15; }
 __host__ __device__ inline int obs_meta_lut_bytes(int N, int M) { return (N * M + 15) & ~15; }
-// scratch of the metadata rows: what k_observe_codes needs per wave
-__host__ __device__ inline int obs_meta_wave_bytes(int RS, int N, int M) {
-    return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_meta_lut_bytes(N, M);
-}
 __host__ __device__ inline int obs_wave_bytes(int RS, int N, int M, int obs_bytes) {
-    return obs_meta_wave_bytes(RS, N, M) + 2 * obs_bitmap_bytes(obs_bytes);
+    return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_meta_lut_bytes(N, M) + obs_bitmap_bytes(obs_bytes);
 }
 
 #define LGKM_ONLY 0xC07F  // s_waitcnt lgkmcnt(0): LDS traffic only — never drain the wave's outstanding stores
 // Profiling-only ablations (never defined in the shipped build; see tools/ablate.sh):
-//   bit0 no bit expansion, bit1 no chunk stores, bit2 no bitmap build, bit3 no metadata, bit4 metadata computed but not stored,
-//   bit5 build and stream as separate phases (round 1's schedule)
+//   bit0 no bit expansion, bit1 no chunk stores, bit2 no bitmap build, bit3 no metadata, bit4 metadata computed but not stored
 #ifndef OBS_ABLATE
 #define OBS_ABLATE 0
 #endif
@@ -811,9 +800,25 @@ __device__ __forceinline__ int flip_cell(const DevCfg& cfg, int cell, int r, int
     if (cfg.flip_axis == 1) return r * G + (G - 1 - c);     // np.flip(plane, 1)
     return (G - 1 - c) * G + (G - 1 - r);                   // np.rot90(plane.T, 2)
 }
+// A load the compiler does not track: issued one env ahead of its use, waited for by obs_prefetch_wait.
+// (vmcnt retires in issue order, so a compiler-placed wait for next env's state would first drain every
+// store of the current env; issued BEFORE those stores and waited for with a counted vmcnt a few
+// stores later, the data is simply there when the wave reaches the next env.)
+__device__ __forceinline__ uint32_t obs_prefetch_dword(const uint32_t* ptr) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+#ifndef OBS_PREFETCH
+#define OBS_PREFETCH 1  // 0 = profiling comparison only (tools/ablate.sh)
+#endif
 #ifndef OBS_UNROLL
 #define OBS_UNROLL 8    // store instructions per pass of the stream loop
 #endif
+#define OBS_PF_WAIT 16  // stream iteration (a multiple of OBS_UNROLL) at which the prefetched state is waited for ...
+// ... with vmcnt(8): the two prefetch loads are older than the >= OBS_PF_WAIT stores issued since
+#define OBS_PREFETCH_WAIT(a, b) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a), "+v"(b)::"memory")
+#define OBS_PREFETCH_DRAIN(a, b) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory")
 
 // 4 bits -> 4 bytes of 0/1: the four shifted copies of the nibble do not overlap, so no carries
 __device__ __forceinline__ uint32_t expand4(uint32_t h, int j) {
@@ -838,10 +843,7 @@ __device__ __forceinline__ ObsSlots obs_slots(const DevCfg& cfg, uint32_t revers
 // Which of the (at most 36 distinct + two constant) values mv[] each element of the N x M metadata block shows
 // (gridworld_ctf.py:1044-1067): mv[0] step fraction, mv[1 + t] capture ratio for a viewer of team t, mv[4 + j] the
 // uint8-truncated hp of agent j, mv[20 + j] has_flag[j], mv[40] = 1.0, mv[41] = 0.0.
-__device__ __forceinline__ void obs_meta_consts(uint16_t* mv, int lane) {
-    if (lane == 0) { mv[40] = 0x3C00u; mv[41] = 0u; }
-}
-__device__ __forceinline__ void obs_meta_lut(const DevCfg& cfg, uint8_t* mlut, int lane) {
+__device__ __forceinline__ void obs_meta_lut(const DevCfg& cfg, uint8_t* mlut, uint16_t* mv, int lane) {
     const int N = cfg.N, M = cfg.M;
     for (int idx = lane; idx < N * M; idx += WAVE) {
         const int i = (int)fdiv((uint32_t)idx, cfg.div_m), k = idx - i * M;
@@ -866,100 +868,103 @@ __device__ __forceinline__ void obs_meta_lut(const DevCfg& cfg, uint8_t* mlut, i
         }
         mlut[idx] = (uint8_t)src;
     }
+    if (lane == 0) { mv[40] = 0x3C00u; mv[41] = 0u; }
 }
 
-// the wave's scratch for one env's metadata rows and bitmaps
-struct ObsLds {
-    uint16_t* mv;        // the few distinct metadata values of one env, as f16 bits
-    uint16_t* mstage;    // the N x M block, assembled
-    const uint8_t* mlut; // element -> index into mv (obs_meta_lut)
-    uint32_t* bits[2];   // two bitmaps: one streaming, one being built
-};
-
-// ---- build step 1: an all-zero bitmap
-__device__ __forceinline__ void obs_zero_bitmap(const DevCfg& cfg, uint32_t* bits, int lane) {
+// Everything of one env except the streaming: bitmap (zero + hot bits + own-position bits) into `bits`, metadata rows
+// to global memory.  `recw` / `cells` are the lane's dword of the env's record / grid (lane-clamped loads).
+// srec / mv / mstage are the calling wave's scratch.  Ends with the wave's LDS traffic drained.
+__device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& p, int e, uint32_t recw, uint32_t cells,
+                                              uint8_t* srec, uint16_t* mv, uint16_t* mstage, const uint8_t* mlut, uint32_t* bits,
+                                              const ObsSlots& slots, uint32_t reverse_mask, int lane, bool obs,
+                                              uint16_t* __restrict__ meta) {
+    const int N = cfg.N, G = cfg.G, GG = cfg.GG, M = cfg.M;
     const int BQ = obs_bitmap_bytes(cfg.obs_bytes) / 16;
-    const u32x4_t z = {0u, 0u, 0u, 0u};
-    for (int q = lane; q < BQ; q += WAVE) ((u32x4_t*)bits)[q] = z;
-}
-
-// ---- build step 2: the hot bits of the 4 cells in grid dword w, for every agent's view
-__device__ __forceinline__ void obs_cell_bits(const DevCfg& cfg, uint32_t* bits, const ObsSlots& slots, uint32_t cells, int w) {
-    const int G = cfg.G, GG = cfg.GG;
-    if (cells == 0) return;
+    const int GW = cfg.GS / 4;  // <= 256 dwords: up to 4 passes of 64 lanes
+    const bool has_cells = obs && !(OBS_ABLATE & 4);
     const uint32_t* slot_agents = slots.a;
-    int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int cell = w * 4 + b;
-        const uint32_t v = (cells >> (8 * b)) & 0xFFu;
-        if (v != 0 && cell < GG) {
-            const int fl = flip_cell(cfg, cell, r, c);
-#pragma unroll
-            for (int slot = 0; slot < 4; slot++) {
-                if (slot_agents[slot]) {  // uniform
-                    // nibble v of the 64-bit LUT with 32-bit ops (a 64-bit variable shift is several times slower)
-                    const uint64_t lut = pin64(cfg.chan_lut[slot >> 1]);
-                    const uint32_t code = (((v & 8u) ? (uint32_t)(lut >> 32) : (uint32_t)lut) >> (4 * (v & 7u))) & 15u;
-                    if (code != CTF_TILE_NONE) {
-                        const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
-                        for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
-                            const uint32_t bit = (uint32_t)(__ffs((int)m) - 1) * (uint32_t)cfg.CGG + q;
-                            atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
+    // ---- zero the bitmap, park the record in LDS
+    if (obs) {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        for (int q = lane; q < BQ; q += WAVE) ((u32x4_t*)bits)[q] = z;
+    }
+    if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
+    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- hot bits of every tile plane
+    if (has_cells) {
+        for (int w = lane; w < GW; w += WAVE) {
+            if (w >= WAVE) cells = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16 only
+            int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
+            #pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int cell = w * 4 + b;
+                const uint32_t v = (cells >> (8 * b)) & 0xFFu;
+                if (v != 0 && cell < GG) {
+                    const int fl = flip_cell(cfg, cell, r, c);
+                    #pragma unroll
+                    for (int slot = 0; slot < 4; slot++) {
+                        if (slot_agents[slot]) {  // uniform
+                            // nibble v of the 64-bit LUT with 32-bit ops (a 64-bit variable shift is several times slower)
+                            const uint64_t lut = pin64(cfg.chan_lut[slot >> 1]);
+                            const uint32_t code = (((v & 8u) ? (uint32_t)(lut >> 32) : (uint32_t)lut) >> (4 * (v & 7u))) & 15u;
+                            if (code != CTF_TILE_NONE) {
+                                const uint32_t q = code * (uint32_t)GG + (uint32_t)((slot & 1) ? fl : cell);
+                                for (uint32_t m = slot_agents[slot]; m; m &= m - 1) {  // uniform loop over the slot's agents
+                                    const uint32_t bit = (uint32_t)(__ffs((int)m) - 1) * (uint32_t)cfg.CGG + q;
+                                    atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
+                                }
+                            }
                         }
                     }
                 }
+                if (++c == G) { c = 0; r++; }
             }
         }
-        if (++c == G) { c = 0; r++; }
     }
-}
-
-// ---- build step 3a: plane 0, the viewer's own position (srec: the env's record in LDS)
-__device__ __forceinline__ void obs_own_bits(const DevCfg& cfg, uint32_t* bits, const uint8_t* srec, uint32_t reverse_mask, int lane) {
-    if (lane < cfg.N) {
-        const int G = cfg.G;
+    // ---- plane 0: the viewer's own position
+    if (obs && lane < N) {
         const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
         const int r = ps[2 * lane], c = ps[2 * lane + 1];
         const int cell = ((reverse_mask >> lane) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c;
         const uint32_t bit = (uint32_t)lane * (uint32_t)cfg.CGG + (uint32_t)cell;
         atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
     }
-}
 
-// ---- build step 3b: the metadata rows of env e (gridworld_ctf.py:1027-1069), from its record in LDS to global memory
-__device__ __forceinline__ void obs_meta_rows(const DevCfg& cfg, int e, const uint8_t* srec, const ObsLds& L, int lane,
-                                              uint16_t* __restrict__ meta) {
-    if (OBS_ABLATE & 8) return;
-    const int N = cfg.N, M = cfg.M;
-    // A: the few distinct values, as f16 bits
-    const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
-    if (lane < 36) {
-        double val = 0.0;
-        if (lane == 0) val = (double)misc[0] / (double)cfg.game_steps;
-        else if (lane < 3) val = (double)(misc[lane] + 1) / (double)(misc[3 - lane] + 1);  // viewer team lane-1
-        else if (lane >= 4 && lane < 4 + N) {
-            // the quirk at :1039-1041: hp of the agent whose INDEX is type(j), over max hp of type(j), as uint8
-            const int tv = cfg_type(cfg, lane - 4);
-            double q = 0.0;
-            if (tv < N) {
-                const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
-                q = __hiloint2double((int)hq[1], (int)hq[0]) / sel4(cfg.type_hp, tv);
-            }
-            val = (double)(uint8_t)(long long)q;
-        } else if (lane >= 20 && lane < 20 + N) val = (double)srec[cfg.off_flag + lane - 20];
-        L.mv[lane] = f64_to_f16(val);
+    // ---- metadata (gridworld_ctf.py:1027-1069).  A: the few distinct values, as f16 bits
+    if (meta && !(OBS_ABLATE & 8)) {
+        const int32_t* misc = (const int32_t*)(srec + cfg.off_misc);
+        if (lane < 36) {
+            double val = 0.0;
+            if (lane == 0) val = (double)misc[0] / (double)cfg.game_steps;
+            else if (lane < 3) val = (double)(misc[lane] + 1) / (double)(misc[3 - lane] + 1);  // viewer team lane-1
+            else if (lane >= 4 && lane < 4 + N) {
+                // the quirk at :1039-1041: hp of the agent whose INDEX is type(j), over max hp of type(j), as uint8
+                const int tv = cfg_type(cfg, lane - 4);
+                double q = 0.0;
+                if (tv < N) {
+                    const uint32_t* hq = (const uint32_t*)(srec + 8 * tv);
+                    q = __hiloint2double((int)hq[1], (int)hq[0]) / sel4(cfg.type_hp, tv);
+                }
+                val = (double)(uint8_t)(long long)q;
+            } else if (lane >= 20 && lane < 20 + N) val = (double)srec[cfg.off_flag + lane - 20];
+            mv[lane] = f64_to_f16(val);
+        }
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+        __builtin_amdgcn_wave_barrier();
+        // B: every element of the N x M block is one of those values (which one: obs_meta_lut, built once per wave)
+        for (int idx = lane; idx < N * M; idx += WAVE) mstage[idx] = mv[mlut[idx]];
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+        __builtin_amdgcn_wave_barrier();
+        // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
+        u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
+        if (!(OBS_ABLATE & 16))
+        for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)mstage)[q];
     }
-    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the bitmap's atomic ORs have landed
     __builtin_amdgcn_wave_barrier();
-    // B: every element of the N x M block is one of those values (which one: obs_meta_lut, built once per wave)
-    for (int idx = lane; idx < N * M; idx += WAVE) L.mstage[idx] = L.mv[L.mlut[idx]];
-    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-    __builtin_amdgcn_wave_barrier();
-    // C: N*M*2 = 4N(N+3) bytes, always a multiple of 8
-    u32x2_t* mdst = (u32x2_t*)(meta + (size_t)e * N * M);
-    if (!(OBS_ABLATE & 16))
-        for (int q = lane; q < N * M / 4; q += WAVE) mdst[q] = ((const u32x2_t*)L.mstage)[q];
+
 }
 
 // one 16-byte chunk of the observation block: h = halfword k of the bitmap, every bit expanded to a byte
@@ -987,192 +992,11 @@ __device__ __forceinline__ void obs_store_chunk(uint8_t* out, uint32_t h, int k,
     }
 }
 
-// OBS_UNROLL store instructions of one env's stream (iterations it0 .. it0 + OBS_UNROLL - 1), their bitmap halfwords read
-// first: the stores then issue back to back instead of each waiting for its own LDS round trip
+// Every wave builds and streams its own envs.  (A builder / streamer split — one wave of a block building the next
+// three envs' bitmaps while the other three stream — was tried and measured 15-25 % slower: a single builder wave's
+// dependent chain is too long, and 24 streaming waves per CU drive the store path less well than 32.)
 template <int ALIGN>
-__device__ __forceinline__ void obs_stream_pass(uint8_t* out, const uint16_t* hb, int k0, int it0, int nchunks, int nfull, int tail,
-                                                int lane, uint32_t& ablate_acc) {
-    uint32_t h[OBS_UNROLL];
-#pragma unroll
-    for (int u = 0; u < OBS_UNROLL; u++) {
-        const int k = k0 + lane + (it0 + u) * WAVE;
-        h[u] = (k >= 0 && k < nchunks) ? hb[k] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < OBS_UNROLL; u++) {
-        const int k = k0 + lane + (it0 + u) * WAVE;
-        if (k >= 0 && k < nchunks) obs_store_chunk<ALIGN>(out, h[u], k, nfull, tail, ablate_acc);
-    }
-}
-
-// A load the compiler does not track.  vmcnt retires in issue order, so a compiler-placed wait for the next env's state
-// would first drain every store the wave has in flight (and with the use inside a loop it waits with vmcnt(0) right after
-// the load).  Issued by hand before a pass of stores and waited for, in straight-line code of the SAME env iteration, with
-// a vmcnt that counts the store instructions issued since, the state simply is there when its build starts and the stores
-// keep draining.  tools/isa_lint.py checks the compiled ISA: nothing may touch the destination registers in between.
-__device__ __forceinline__ uint32_t obs_untracked_dword(const uint32_t* ptr) {
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
-
-// Where a wave's envs come from.  Both sources present env i of the wave's sequence as: its global index, its record in
-// LDS, and its grid as dwords.
-//   ObsFromGlobal  the standalone render: the lane's dwords of the NEXT env's record / grid are loaded by hand (issue)
-//                  before a pass of stores, waited for two passes later (wait) and parked in LDS when that env's
-//                  build reaches them;
-//   ObsFromLds     the fused step + render launch: the step phase left every env's grid and record in LDS.
-struct ObsFromGlobal {
-    const DevCfg& cfg;
-    const DevPtrs& p;
-    int e_first, e_stride, count;
-    uint8_t* srec;       // LDS: the record of the env being built
-    uint32_t recw;       // the lane's (clamped) dword of the record of the env last issued
-    uint32_t cells[4];   // ... and of its grid: dwords lane, lane + 64, ... (G <= 32: at most 256 dwords)
-    int rec_lane, lane;
-    __device__ __forceinline__ int env(int i) const { return e_first + i * e_stride; }
-    __device__ __forceinline__ void issue(int i) {  // i < count
-        const int e = env(i);
-        const int GW = cfg.GS / 4;
-        const uint32_t* g = (const uint32_t*)(p.grid + (size_t)e * cfg.GS);
-        recw = obs_untracked_dword((const uint32_t*)(p.rec + (size_t)e * cfg.RS) + rec_lane);
-        cells[0] = obs_untracked_dword(g + min(lane, GW - 1));
-        if (GW > WAVE) cells[1] = obs_untracked_dword(g + min(lane + WAVE, GW - 1));  // uniform conditions
-        if (GW > 2 * WAVE) cells[2] = obs_untracked_dword(g + min(lane + 2 * WAVE, GW - 1));
-        if (GW > 3 * WAVE) cells[3] = obs_untracked_dword(g + min(lane + 3 * WAVE, GW - 1));
-    }
-    // `stores` = 2 * OBS_UNROLL store instructions have certainly been issued since issue(): a counted wait; else drain
-    // ONE statement ties the registers, executed on every path (two alternative tied waits would merge their outputs
-    // through copies placed before the wait); the drain for the short-stream case carries no register operands.
-    __device__ __forceinline__ void wait(bool counted) {
-        if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt vmcnt(%c5)" : "+v"(recw), "+v"(cells[0]), "+v"(cells[1]), "+v"(cells[2]), "+v"(cells[3]) : "n"(2 * OBS_UNROLL) : "memory");
-    }
-    __device__ __forceinline__ const uint8_t* record(int) {  // parks the record in LDS
-        if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-        __builtin_amdgcn_wave_barrier();
-        return srec;
-    }
-    __device__ __forceinline__ void cell_bits(int, uint32_t* bits, const ObsSlots& slots) const {
-        const int GW = cfg.GS / 4;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int w = lane + WAVE * j;
-            // opaque per env: otherwise the cell geometry (flips, bit offsets of every agent's view) of all four dwords is
-            // hoisted out of the env loop into ~100 registers
-            asm volatile("" : "+v"(w));
-            if (GW > WAVE * j && w < GW) obs_cell_bits(cfg, bits, slots, cells[j], w);
-        }
-    }
-};
-struct ObsFromLds {
-    const DevCfg& cfg;
-    int env0, count;
-    const uint8_t* state;  // LDS: slot k = [grid GS][rec RS] of env env0 + k
-    int stride;            // bytes between slots
-    int first, every;      // this wave's envs: slots first, first + every, ...
-    int lane;
-    __device__ __forceinline__ int slot(int i) const { return first + i * every; }
-    __device__ __forceinline__ int env(int i) const { return env0 + slot(i); }
-    __device__ __forceinline__ void issue(int) {}
-    __device__ __forceinline__ void wait(bool) {}
-    __device__ __forceinline__ const uint8_t* record(int i) { return state + (size_t)slot(i) * stride + cfg.GS; }
-    __device__ __forceinline__ void cell_bits(int i, uint32_t* bits, const ObsSlots& slots) const {
-        const uint32_t* g = (const uint32_t*)(state + (size_t)slot(i) * stride);
-        const int GW = cfg.GS / 4;
-        for (int w0 = lane; w0 < GW; w0 += WAVE) {
-            int w = w0;
-            asm volatile("" : "+v"(w));  // as in ObsFromGlobal::cell_bits
-            obs_cell_bits(cfg, bits, slots, g[w], w);
-        }
-    }
-};
-
-// One of the three build steps of env i of the sequence into `bits` (ends with the wave's LDS traffic drained).
-template <class Src>
-__device__ __forceinline__ void obs_build_step(const DevCfg& cfg, Src& src, int i, int step, const ObsLds& L, uint32_t* bits,
-                                               const ObsSlots& slots, uint32_t reverse_mask, int lane, bool obs,
-                                               uint16_t* __restrict__ meta) {
-    if (step == 0) {
-        if (obs) obs_zero_bitmap(cfg, bits, lane);
-    } else if (step == 1) {
-        if (obs && !(OBS_ABLATE & 4)) src.cell_bits(i, bits, slots);
-    } else {
-        const uint8_t* srec = src.record(i);
-        if (obs) obs_own_bits(cfg, bits, srec, reverse_mask, lane);
-        if (meta) obs_meta_rows(cfg, src.env(i), srec, L, lane, meta);
-    }
-    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Renders the wave's sequence of envs: env i streams out of one bitmap while env i + 1 is built into the other, one build
-// step after each of the first three passes of OBS_UNROLL store instructions (iteration i = -1 only builds env 0).  The
-// zeroing needs nothing of the next env's state and goes first; the global source's state loads are issued before pass 0
-// and waited for after pass 1, all in straight-line code.
-template <int ALIGN, class Src>
-__device__ __forceinline__ void obs_render_sequence(const DevCfg& cfg, Src& src, const ObsLds& L, const ObsSlots& slots,
-                                                    uint32_t reverse_mask, int lane, uint8_t* __restrict__ obs,
-                                                    uint16_t* __restrict__ meta) {
-    const int count = src.count;
-    if (count <= 0) return;
-    const bool want_obs = obs != nullptr;
-    const int nfull = cfg.obs_bytes >> 4;
-    const int tail = cfg.obs_bytes & 15;
-    const int nchunks = nfull + (tail ? 1 : 0);
-    uint32_t ablate_acc = 0;
-#pragma unroll 1
-    for (int i = -1; i < count; i++) {
-        const bool has_next = i + 1 < count;
-        uint32_t* nbits = ((i + 1) & 1) ? L.bits[1] : L.bits[0];
-        // 16 bytes per lane per store.  Wave store instructions are aligned to 1 KiB of the flat output (k starts
-        // negative), so only an env's first and last instruction touch a partial line.
-        const bool streaming = want_obs && i >= 0;
-        const size_t base = (size_t)src.env(streaming ? i : 0) * cfg.obs_bytes;
-        uint8_t* out = obs + base;
-        const uint16_t* hb = (const uint16_t*)((i & 1) ? L.bits[1] : L.bits[0]);
-        const int k0 = (ALIGN >= 16) ? -(int)(((base + (uintptr_t)obs) >> 4) & 63) : 0;
-        const int niter = streaming ? (nchunks - k0 + WAVE - 1) / WAVE : 0;
-        const int npass = (niter + OBS_UNROLL - 1) / OBS_UNROLL;
-        src.issue(has_next ? i + 1 : i);  // unconditional (the last env loads itself again): issue and wait on every path
-        if (OBS_ABLATE & 32) {  // round 1's schedule: the whole stream, then the whole build
-#pragma unroll 1
-            for (int ps = 0; ps < npass; ps++) obs_stream_pass<ALIGN>(out, hb, k0, ps * OBS_UNROLL, nchunks, nfull, tail, lane, ablate_acc);
-            src.wait(false);
-            if (has_next) {
-                for (int st = 0; st < 3; st++) obs_build_step(cfg, src, i + 1, st, L, nbits, slots, reverse_mask, lane, want_obs, meta);
-            }
-            continue;
-        }
-        if (npass > 0) obs_stream_pass<ALIGN>(out, hb, k0, 0, nchunks, nfull, tail, lane, ablate_acc);
-        if (has_next) obs_build_step(cfg, src, i + 1, 0, L, nbits, slots, reverse_mask, lane, want_obs, meta);
-        if (npass > 1) obs_stream_pass<ALIGN>(out, hb, k0, OBS_UNROLL, nchunks, nfull, tail, lane, ablate_acc);
-        // every store instruction of iterations 0 .. niter - 1 is issued (at least one lane is in range): with
-        // niter >= 2 * OBS_UNROLL the loads have 2 * OBS_UNROLL stores behind them
-        src.wait(niter >= 2 * OBS_UNROLL);
-        if (has_next) obs_build_step(cfg, src, i + 1, 1, L, nbits, slots, reverse_mask, lane, want_obs, meta);
-        if (npass > 2) obs_stream_pass<ALIGN>(out, hb, k0, 2 * OBS_UNROLL, nchunks, nfull, tail, lane, ablate_acc);
-        if (has_next) obs_build_step(cfg, src, i + 1, 2, L, nbits, slots, reverse_mask, lane, want_obs, meta);
-#pragma unroll 1
-        for (int ps = 3; ps < npass; ps++) obs_stream_pass<ALIGN>(out, hb, k0, ps * OBS_UNROLL, nchunks, nfull, tail, lane, ablate_acc);
-    }
-    if ((OBS_ABLATE & 2) && ablate_acc == 0x12345678u) obs[lane] = 1;  // keeps the ablated work alive
-}
-
-__device__ __forceinline__ ObsLds obs_lds_carve(uint8_t* base, int N, int M, int obs_bytes) {
-    ObsLds L;
-    L.mv = (uint16_t*)base;
-    L.mstage = (uint16_t*)(base + OBS_MV_BYTES);
-    uint8_t* mlut = base + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
-    L.mlut = mlut;
-    L.bits[0] = (uint32_t*)(mlut + obs_meta_lut_bytes(N, M));
-    L.bits[1] = (uint32_t*)((uint8_t*)L.bits[0] + obs_bitmap_bytes(obs_bytes));
-    return L;
-}
-
-template <int ALIGN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_observe(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs,
+__global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs,
                                                  uint16_t* __restrict__ meta, uint32_t reverse_mask) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1180,206 +1004,77 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int wpb = blockDim.x / WAVE;
     const int N = cfg.N, M = cfg.M;
     uint8_t* wl = (uint8_t*)lds + wave * obs_wave_bytes(cfg.RS, N, M, cfg.obs_bytes);
-    const ObsLds L = obs_lds_carve(wl + cfg.RS, N, M, cfg.obs_bytes);
+    uint8_t* srec = wl;
+    uint16_t* mv = (uint16_t*)(wl + cfg.RS);
+    uint16_t* mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
+    uint8_t* mlut = wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
+    uint32_t* bits = (uint32_t*)(mlut + obs_meta_lut_bytes(N, M));
     const ObsSlots slots = obs_slots(cfg, reverse_mask);
-    if (meta) { obs_meta_lut(cfg, (uint8_t*)L.mlut, lane); obs_meta_consts(L.mv, lane); }
+    if (meta) obs_meta_lut(cfg, mlut, mv, lane);
+    const int GW = cfg.GS / 4;
+    const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
     const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
-    const int count = e_first < cfg.n_envs ? (cfg.n_envs - e_first + e_stride - 1) / e_stride : 0;
-    ObsFromGlobal src = {cfg, p, e_first, e_stride, count, wl, 0u, {0u, 0u, 0u, 0u}, min(lane, cfg.RS / 4 - 1), lane};
-    obs_render_sequence<ALIGN>(cfg, src, L, slots, reverse_mask, lane, obs, meta);
-}
-
-// ------------------------------------------------------------------------------------------------
-// step + observe in ONE launch
-// ------------------------------------------------------------------------------------------------
-// One block per group of 64 / W envs, one-shot.  Wave 0 stages the group into LDS, steps it (env_step, W lanes per env)
-// and writes grid / record / RNG state back while the block's other waves wait at the barrier (a waiting wave costs no
-// issue slot); then ALL the block's waves render the group's envs straight from LDS (obs_render_sequence, ObsFromLds:
-// wave w takes envs w, w + wpb, ...): no second launch, no re-read of the state.  Blocks are independent, so after the
-// first round the resident blocks of a CU are at different points of their step / render cycle and the store streams of
-// the rendering blocks cover the latency chain of the stepping ones.
-//
-// Per-block LDS: [state: EPW x (grid GS + rec RS), odd dword stride][union: step scratch EPW x (actions 16 + two RNG
-// windows + metric deltas) | render scratch wpb x (mvals, meta staging, two bitmaps)][meta source LUT]
-__host__ __device__ inline int fused_state_stride(int GS, int RS) {
-    int b = GS + RS;
-    if (((b / 4) & 1) == 0) b += 4;
-    return b;
-}
-__host__ __device__ inline int fused_scratch_stride(int N, bool metrics) {
-    int b = 16 + 2 * WCAP * 4 + (metrics ? ((CTF_N_METRICS * N + 3) & ~3) : 0);
-    if (((b / 4) & 1) == 0) b += 4;
-    return b;
-}
-__host__ __device__ inline int fused_render_bytes(int N, int M, int obs_bytes) {
-    return OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + 2 * obs_bitmap_bytes(obs_bytes);
-}
-__host__ __device__ inline int fused_block_bytes(int epw, int wpb, int GS, int RS, int N, int M, int obs_bytes, bool metrics) {
-    const int a = epw * fused_scratch_stride(N, metrics), b = wpb * fused_render_bytes(N, M, obs_bytes);
-    return ((epw * fused_state_stride(GS, RS) + (a > b ? a : b) + 15) & ~15) + obs_meta_lut_bytes(N, M);
-}
-
-template <bool METRICS, int W, int ALIGN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_step_observe(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
-                                                      float* __restrict__ rw32, double* __restrict__ rw64,
-                                                      uint8_t* __restrict__ done_out, uint32_t flags, uint8_t* __restrict__ obs,
-                                                      uint16_t* __restrict__ meta, uint32_t reverse_mask) {
-    constexpr int EPW = WAVE / W;  // envs per group
-    extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-    const int wpb = blockDim.x / WAVE;
-    const int N = cfg.N, M = cfg.M;
-    const int SS = fused_state_stride(cfg.GS, cfg.RS), CS = fused_scratch_stride(N, METRICS);
-    const int SSW = SS / 4, CSW = CS / 4, GW = cfg.GS / 4, RW = cfg.RS / 4;
-    const int block_bytes = fused_block_bytes(EPW, wpb, cfg.GS, cfg.RS, N, M, cfg.obs_bytes, METRICS);
-    uint8_t* bl = (uint8_t*)lds;
-    uint32_t* state = (uint32_t*)bl;
-    uint8_t* uni = bl + EPW * SS;
-    uint32_t* scratch = (uint32_t*)uni;
-    uint8_t* mlut = bl + block_bytes - obs_meta_lut_bytes(N, M);
-    const int env0 = blockIdx.x * EPW;
-    const int nvalid = min(EPW, cfg.n_envs - env0);
-
-    if (wave == 0) {
-        const int g = lane / W, j = lane % W;
-        const int e = env0 + g;
-        // ---- stage the group's grids, records and actions into LDS (flat 16-byte loads, several in flight per lane)
-        {
-            const u32x4_t* gsrc = (const u32x4_t*)(p.grid + (size_t)env0 * cfg.GS);
-            const u32x4_t* rsrc = (const u32x4_t*)(p.rec + (size_t)env0 * cfg.RS);
-            const int GQ = GW / 4, RQ = RW / 4;
-            const int ng = nvalid * GQ, nr = nvalid * RQ;
-#pragma unroll 4
-            for (int q = lane; q < ng; q += WAVE) {
-                const u32x4_t v = gsrc[q];
-                const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
-                uint32_t* slot = state + el * SSW + w;
-                slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
-            }
-#pragma unroll 2
-            for (int q = lane; q < nr; q += WAVE) {
-                const u32x4_t v = rsrc[q];
-                const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
-                uint32_t* slot = state + el * SSW + GW + w;
-                slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
-            }
-            const int8_t* asrc = actions + (size_t)env0 * N;
-#pragma unroll 2
-            for (int idx = lane; idx < nvalid * N; idx += WAVE) {
-                const int el = (int)fdiv((uint32_t)idx, cfg.div_n), i = idx - el * N;
-                ((int8_t*)(scratch + el * CSW))[i] = asrc[idx];
-            }
-            if (METRICS) {
-                const int MW = (CTF_N_METRICS * N + 3) / 4;
-                for (int idx = lane; idx < nvalid * MW; idx += WAVE) {
-                    const int el = (int)fdiv((uint32_t)idx, cfg.div_mw), w = idx - el * MW;
-                    scratch[el * CSW + 4 + 2 * WCAP + w] = 0;
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-        __builtin_amdgcn_wave_barrier();
-
-        if (g < nvalid) {
-            StepCtx<W> s;
-            s.sg = (uint8_t*)(state + g * SSW);
-            s.sr = s.sg + cfg.GS;
-            uint32_t* wins = scratch + g * CSW + 4;
-            s.sm = METRICS ? (uint8_t*)(wins + 2 * WCAP) : nullptr;
-            s.j = j;
-            s.gshift = g * W;
-            s.lead = (j == 0);
-            const int8_t* act = (const int8_t*)(scratch + g * CSW);
-            int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
-
-            MtWin py = mtw_open(p.mt_py + (size_t)e * CTF_MT_N, wins, p.rngpos[2 * e]);
-            MtWin npg = mtw_open(p.mt_np + (size_t)e * CTF_MT_N, wins + WCAP, p.rngpos[2 * e + 1]);
-
-            if ((flags & CTF_STEP_AUTO_RESET) && (misc[3] & CTF_F_DONE)) {
-                const uint32_t* src = (const uint32_t*)p.init_grid;
-                for (int w = j; w < GW; w += W) ((uint32_t*)s.sg)[w] = src[w];
-                if (s.lead) reset_record(cfg, s.sr);
-                if (METRICS) {
-                    int32_t* m = p.metrics + (size_t)e * CTF_N_METRICS * N;
-                    for (int w = j; w < CTF_N_METRICS * N; w += W) m[w] = 0;
-                }
-            }
-
-            uint32_t status = 0;
-            env_step<METRICS, W>(cfg, p, s, act, py, npg, status, e, rw32, rw64, done_out);
-            mtw_flush<W>(py, j);
-            mtw_flush<W>(npg, j);
-            if (s.lead) {
-                p.rngpos[2 * e] = py.pos | (py.lazy ? CTF_LAZY_BIT : 0u);
-                p.rngpos[2 * e + 1] = npg.pos | (npg.lazy ? CTF_LAZY_BIT : 0u);
-                if (status) atomicOr(p.status, status);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- the stepped state goes back to HBM (flat 16-byte stores); the LDS copy stays for the render
-        {
-            u32x4_t* gdst = (u32x4_t*)(p.grid + (size_t)env0 * cfg.GS);
-            u32x4_t* rdst = (u32x4_t*)(p.rec + (size_t)env0 * cfg.RS);
-            const int GQ = GW / 4, RQ = RW / 4;
-            const int ng = nvalid * GQ, nr = nvalid * RQ;
-#pragma unroll 2
-            for (int q = lane; q < ng; q += WAVE) {
-                const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
-                const uint32_t* slot = state + el * SSW + w;
-                const u32x4_t v = {slot[0], slot[1], slot[2], slot[3]};
-                gdst[q] = v;
-            }
-#pragma unroll 2
-            for (int q = lane; q < nr; q += WAVE) {
-                const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
-                const uint32_t* slot = state + el * SSW + GW + w;
-                const u32x4_t v = {slot[0], slot[1], slot[2], slot[3]};
-                rdst[q] = v;
-            }
-            if (METRICS) {
-                const int MN = CTF_N_METRICS * N;
-                int32_t* mdst = p.metrics + (size_t)env0 * MN;
-                if ((MN & 1) == 0) {
-                    for (int idx = lane; idx < nvalid * MN / 2; idx += WAVE) {
-                        const int el = (int)fdiv((uint32_t)(2 * idx), cfg.div_mn), w = 2 * idx - el * MN;
-                        const uint8_t* d = (const uint8_t*)(scratch + el * CSW + 4 + 2 * WCAP) + w;
-                        const unsigned long long inc = (unsigned long long)d[0] | ((unsigned long long)d[1] << 32);
-                        if (inc) atomicAdd((unsigned long long*)(mdst + 2 * idx), inc);
-                    }
-                } else {
-                    for (int idx = lane; idx < nvalid * MN; idx += WAVE) {
-                        const int el = (int)fdiv((uint32_t)idx, cfg.div_mn), w = idx - el * MN;
-                        const uint8_t inc = ((const uint8_t*)(scratch + el * CSW + 4 + 2 * WCAP))[w];
-                        if (inc) atomicAdd(mdst + idx, (int32_t)inc);
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the step scratch has been read: the render may take its place
-    } else if (wave == wpb - 1 && meta) {
-        obs_meta_lut(cfg, mlut, lane);  // meanwhile: which value every element of a metadata block shows
+    const int e_end = cfg.n_envs;
+    // the first env's state: ordinary loads; every later env's state arrives through the prefetch below
+    uint32_t recw = 0, cells = 0;
+    if (e_first < e_end) {
+        recw = ((const uint32_t*)(p.rec + (size_t)e_first * cfg.RS))[rec_lane];
+        cells = ((const uint32_t*)(p.grid + (size_t)e_first * cfg.GS))[grid_lane];
     }
-    __syncthreads();
 
-    // ---- all waves render the group's envs from LDS: wave w takes envs w, w + wpb, ...
-    uint8_t* rs = uni + wave * fused_render_bytes(N, M, cfg.obs_bytes);
-    ObsLds L;
-    L.mv = (uint16_t*)rs;
-    L.mstage = (uint16_t*)(rs + OBS_MV_BYTES);
-    L.mlut = mlut;
-    L.bits[0] = (uint32_t*)(rs + OBS_MV_BYTES + obs_meta_stage_bytes(N, M));
-    L.bits[1] = (uint32_t*)((uint8_t*)L.bits[0] + obs_bitmap_bytes(cfg.obs_bytes));
-    if (meta && wpb == 1) obs_meta_lut(cfg, mlut, lane);
-    if (meta) obs_meta_consts(L.mv, lane);
-    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-    __builtin_amdgcn_wave_barrier();
-    const ObsSlots slots = obs_slots(cfg, reverse_mask);
-    const int count = wave < nvalid ? (nvalid - wave + wpb - 1) / wpb : 0;
-    ObsFromLds src = {cfg, env0, count, (const uint8_t*)state, SS, wave, wpb, lane};
-    obs_render_sequence<ALIGN>(cfg, src, L, slots, reverse_mask, lane, obs, meta);
+    for (int e = e_first; e < e_end; e += e_stride) {
+        obs_build_env(cfg, p, e, recw, cells, srec, mv, mstage, mlut, bits, slots, reverse_mask, lane, obs != nullptr, meta);
+
+        // ---- stream the observation block: 16 bytes per lane per store.  Wave store instructions are
+        // aligned to 1 KiB of the flat output (k starts negative), so only an env's first and last
+        // instruction touch a partial line.
+        if (obs) {
+            const size_t base = (size_t)e * cfg.obs_bytes;
+            uint8_t* out = obs + base;
+            const uint16_t* hb = (const uint16_t*)bits;
+            const int nfull = cfg.obs_bytes >> 4;
+            const int tail = cfg.obs_bytes & 15;
+            const int nchunks = nfull + (tail ? 1 : 0);
+            const int k0 = (ALIGN >= 16) ? -(int)(((base + (uintptr_t)obs) >> 4) & 63) : 0;
+            uint32_t ablate_acc = 0;
+            const int niter = (nchunks - k0 + WAVE - 1) / WAVE;
+            const int e_next = min(e + e_stride, e_end - 1);
+            uint32_t nrec = 0, ncells = 0;
+            // OBS_UNROLL store instructions per pass, their bitmap halfwords read first: the stores then issue back to back
+            // instead of each waiting for its own LDS round trip
+            for (int it0 = 0; it0 < niter; it0 += OBS_UNROLL) {
+                if (OBS_PREFETCH && it0 == 0) {  // next env's state: issued before this env's first store
+                    nrec = obs_prefetch_dword((const uint32_t*)(p.rec + (size_t)e_next * cfg.RS) + rec_lane);
+                    ncells = obs_prefetch_dword((const uint32_t*)(p.grid + (size_t)e_next * cfg.GS) + grid_lane);
+                }
+                if (OBS_PREFETCH && it0 == OBS_PF_WAIT) OBS_PREFETCH_WAIT(nrec, ncells);
+                uint32_t h[OBS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < OBS_UNROLL; u++) {
+                    const int k = k0 + lane + (it0 + u) * WAVE;
+                    h[u] = (k >= 0 && k < nchunks) ? hb[k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < OBS_UNROLL; u++) {
+                    const int k = k0 + lane + (it0 + u) * WAVE;
+                    if (k >= 0 && k < nchunks) obs_store_chunk<ALIGN>(out, h[u], k, nfull, tail, ablate_acc);
+                }
+            }
+            if ((OBS_ABLATE & 2) && ablate_acc == 0x12345678u) out[lane] = 1;  // keeps the ablated work alive
+            if (OBS_PREFETCH) {
+                if (niter <= OBS_PF_WAIT) OBS_PREFETCH_DRAIN(nrec, ncells);
+                recw = nrec;
+                cells = ncells;
+            } else if (e + e_stride < e_end) {
+                recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
+                cells = ((const uint32_t*)(p.grid + (size_t)(e + e_stride) * cfg.GS))[grid_lane];
+            }
+        } else if (e + e_stride < e_end) {
+            recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
+        }
+        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // this env's LDS reads are done before the next env reuses the bitmap
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1391,11 +1086,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 // A policy that consumes the codes directly (ctf_policy.hip) never needs the 14x larger one-hot block.
 // Per env a wave builds the (viewer team, reversed?) code maps that are in use (at most 4) in LDS; every agent's row is
 // its map plus the own-position bit: an output dword is two aligned dwords of the map funnel-shifted (v_alignbyte_b32).
-// The metadata rows leave in the same launch (obs_meta_rows).  Per-wave LDS:
+// The metadata rows leave in the same launch.  Per-wave LDS: obs_build_env's metadata scratch ...
+// ... and the metadata scratch of obs_build_env when the launch also writes the metadata rows:
 // [rec RS][mvals 96][meta staging][meta LUT][grid GS][self cell u16[16]][maps 4 x (GGp + 4)]
 __host__ __device__ inline int codes_map_stride(int GG) { return ((GG + 3) & ~3) + 4; }  // + 4: the funnel read's second dword
 __host__ __device__ inline int codes_wave_bytes(int GS, int RS, int GG, int N, int M) {
-    return obs_meta_wave_bytes(RS, N, M) + GS + 32 + 4 * codes_map_stride(GG);
+    return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_meta_lut_bytes(N, M) + GS + 32 + 4 * codes_map_stride(GG);
 }
 
 template <bool DWORDS>
@@ -1409,19 +1105,16 @@ __global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, ui
     const int N = cfg.N, M = cfg.M, G = cfg.G, GG = cfg.GG, MS = codes_map_stride(GG);
     uint8_t* wl = (uint8_t*)lds + wave * codes_wave_bytes(cfg.GS, cfg.RS, GG, N, M);
     uint8_t* srec = wl;
-    ObsLds L;
-    L.mv = (uint16_t*)(wl + cfg.RS);
-    L.mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
+    uint16_t* mv = (uint16_t*)(wl + cfg.RS);
+    uint16_t* mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
     uint8_t* mlut = wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
-    L.mlut = mlut;
-    L.bits[0] = L.bits[1] = nullptr;
     uint8_t* sgrid = mlut + obs_meta_lut_bytes(N, M);
     uint16_t* selfc = (uint16_t*)(sgrid + cfg.GS);
     uint8_t* maps = (uint8_t*)(selfc + 16);
     const ObsSlots slots = obs_slots(cfg, reverse_mask);
     uint32_t slot_pack = 0;  // 2 bits per agent
     for (int i = 0; i < N; i++) slot_pack |= (uint32_t)(cfg.team[i] * 2 + (int)((reverse_mask >> i) & 1u)) << (2 * i);
-    if (meta) { obs_meta_lut(cfg, mlut, lane); obs_meta_consts(L.mv, lane); }
+    if (meta) obs_meta_lut(cfg, mlut, mv, lane);
     const int row = N * GG;
     const int GW = cfg.GS / 4;
     const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
@@ -1439,13 +1132,8 @@ __global__ void __launch_bounds__(256) k_observe_codes(DevCfg cfg, DevPtrs p, ui
         cells_n = ((const uint32_t*)(p.grid + (size_t)e_next * cfg.GS))[grid_lane];
         if (lane < GW) ((uint32_t*)sgrid)[lane] = cells;
         for (int w = lane + WAVE; w < GW; w += WAVE) ((uint32_t*)sgrid)[w] = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16
-        // park the record in LDS and, when asked for, write this env's metadata rows
-        if (lane < cfg.RS / 4) ((uint32_t*)srec)[lane] = recw;
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-        __builtin_amdgcn_wave_barrier();
-        if (meta) obs_meta_rows(cfg, e, srec, L, lane, meta);
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
-        __builtin_amdgcn_wave_barrier();
+        // parks the record in LDS and, when asked for, writes this env's metadata rows
+        obs_build_env(cfg, p, e, recw, 0u, srec, mv, mstage, mlut, nullptr, slots, reverse_mask, lane, false, meta);
         if (!codes && !selfcells) continue;
         if (lane < N) {
             const int8_t* ps = (const int8_t*)(srec + cfg.off_pos);
@@ -1597,39 +1285,23 @@ static int obs_reserve_blocks() {
     static const int v = [] { const char* e = getenv("CTF_OBS_RESERVE_BLOCKS"); return e ? atoi(e) : 0; }();
     return v < 0 ? 0 : v;
 }
-static int obs_align(const DevCfg& cfg, const uint8_t* obs) {
-    const uintptr_t a = (uintptr_t)obs;
-    return ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0) ? 16 : (((cfg.obs_bytes % 4) == 0 && (a % 4) == 0) ? 4 : 1);
-}
-// resident blocks per CU of `kernel` at this block size / dynamic LDS, as the runtime computes it
-template <class K>
-static int blocks_per_cu(K kernel, int threads, size_t lds_bytes) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds_bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return 0;
-    }
-    return n;
-}
 extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask,
                                          int n_cus, hipStream_t st) {
-    const int align = obs_align(cfg, obs);
-    // waves per block: 4 unless one env's two bitmaps are so large that 4 waves' worth would crowd the CU's LDS
+    const uintptr_t a = (uintptr_t)obs;
+    const int align = ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0) ? 16 : (((cfg.obs_bytes % 4) == 0 && (a % 4) == 0) ? 4 : 1);
+    // waves per block: 4 unless one env's bitmap is so large that 4 of them would crowd the CU's LDS
     const int per_wave = obs_wave_bytes(cfg.RS, cfg.N, cfg.M, cfg.obs_bytes);
     int wpb = 4;
     while (wpb > 1 && wpb * per_wave > 40 * 1024) wpb >>= 1;
     const size_t sh = (size_t)wpb * per_wave;
     int blocks = (cfg.n_envs + wpb - 1) / wpb;
-    // as many blocks as the CU's LDS holds (<= 32 waves), grid-stride beyond that; a few block slots may be left free so
-    // that a concurrent small kernel (the RCCL all-gather of the rollout tensors) can start beside this launch
-    int per_cu = (int)((160 * 1024) / (sh + 1024));
-    if (per_cu > 32 / wpb) per_cu = 32 / wpb;
-    if (per_cu < 1) per_cu = 1;
+    // the CU's 32-wave limit, grid-stride beyond that; a few block slots stay free so that a concurrent small kernel
+    // (the RCCL all-gather of the rollout tensors) can start beside this launch instead of behind it
+    int cap = n_cus * (32 / wpb);
     if (const char* ov = getenv("CTF_OBS_BLOCKS_PER_CU")) {  // profiling only: occupancy scaling of the render
         const int v = atoi(ov);
-        if (v >= 1 && v < per_cu) per_cu = v;
+        if (v >= 1 && v < 32 / wpb) cap = n_cus * v;
     }
-    int cap = n_cus * per_cu;
     if (cap > 64) cap -= obs_reserve_blocks();
     if (blocks > cap) blocks = cap;
     const dim3 grid(blocks), block(wpb * WAVE);
@@ -1637,53 +1309,6 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     else if (align == 4) hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
     return hipGetLastError();
-}
-
-// step + observe in one launch.  *launched = 0 (and nothing enqueued) when this configuration is better served by the
-// two separate launches: unaligned observation blocks, a group's LDS not fitting, or a batch too small to give every
-// wave slot a group (a wave renders its group's envs one after the other).
-template <bool METRICS, int W>
-static hipError_t launch_fused_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done,
-                                 uint32_t flags, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask, int n_cus, hipStream_t st,
-                                 int* launched) {
-    constexpr int EPW = WAVE / W;
-    // waves per block: as many as share the group's envs evenly, while the block's LDS leaves room for >= 3 blocks per CU
-    int wpb = EPW < 4 ? EPW : 4;
-    while (wpb > 1 && fused_block_bytes(EPW, wpb, cfg.GS, cfg.RS, cfg.N, cfg.M, cfg.obs_bytes, METRICS) > 48 * 1024) wpb >>= 1;
-    const size_t sh = (size_t)fused_block_bytes(EPW, wpb, cfg.GS, cfg.RS, cfg.N, cfg.M, cfg.obs_bytes, METRICS);
-    const bool plan_only = *launched < 0;  // query: report what would be launched, enqueue nothing
-    *launched = 0;
-    if (sh > 64 * 1024) return hipSuccess;
-    auto kernel = k_step_observe<METRICS, W, 16>;
-    const int ngroups = (cfg.n_envs + EPW - 1) / EPW;
-    const char* fenv = getenv("CTF_FUSED");  // 0 / 1: never / always (tests, profiling); unset: by batch size
-    const int force = fenv ? atoi(fenv) : -1;
-    if (force == 0) return hipSuccess;
-    // a batch that does not give every CU several groups is better served by the two launches (each of which spreads its
-    // envs over all the waves of the chip)
-    if (force != 1 && ngroups < 4 * n_cus) return hipSuccess;
-    *launched = 1;
-    if (plan_only) return hipSuccess;
-    hipLaunchKernelGGL(kernel, dim3(ngroups), dim3(wpb * WAVE), sh, st, cfg, p, actions, rw32, rw64, done, flags, obs, meta, reverse_mask);
-    return hipGetLastError();
-}
-template <bool METRICS>
-static hipError_t launch_fused_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                                 uint8_t* done, uint32_t flags, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask, int n_cus,
-                                 hipStream_t st, int* launched) {
-    if (w <= 1) return launch_fused_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, obs, meta, reverse_mask, n_cus, st, launched);
-    if (w == 2) return launch_fused_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, obs, meta, reverse_mask, n_cus, st, launched);
-    if (w == 4) return launch_fused_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, obs, meta, reverse_mask, n_cus, st, launched);
-    return launch_fused_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, obs, meta, reverse_mask, n_cus, st, launched);
-}
-extern "C" hipError_t ctf_launch_step_observe(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                                              uint8_t* done, uint32_t flags, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask,
-                                              int n_cus, hipStream_t st, int* launched) {
-    // *launched: in < 0 = plan only; out 1 = the fused kernel was (would be) launched, 0 = use the two separate launches
-    if (!obs || obs_align(cfg, obs) != 16) { *launched = 0; return hipSuccess; }
-    const int w = step_lanes(cfg);
-    if (cfg.log_metrics) return launch_fused_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, obs, meta, reverse_mask, n_cus, st, launched);
-    return launch_fused_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, obs, meta, reverse_mask, n_cus, st, launched);
 }
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint16_t* meta, uint16_t* selfcells,
                                                uint32_t reverse_mask, int n_cus, hipStream_t st) {

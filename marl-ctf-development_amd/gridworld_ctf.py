@@ -247,13 +247,6 @@ class VecGridworldCtf:
                                               _abi.STEP_AUTO_RESET if auto_reset else 0, self._stream()), self._lib)
         return self.rewards, self.done, self.obs, self.meta
 
-    def step_observe_launches(self):
-        """1 when ``step_observe`` runs as the single fused launch for this batch and observation buffer, else 2."""
-        n = self._lib.ctf_step_observe_launches(self._h, C.c_void_p(self.obs.data_ptr()))
-        if n < 0:
-            _abi.check(n, self._lib)
-        return n
-
     def random_actions(self, out, seed, step, env_offset=0):
         """Fill ``out`` (int8 [E, N]) with the synthetic Philox action stream of bench.py / the tests."""
         a = self._check_dev(out, _torch().int8, self.n_envs * self.N_AGENTS)

@@ -107,17 +107,11 @@ def test_golden_trajectory(name):
     ("syn_edge_k1", 64, 150, True),
     ("donut_1v1", 77, 110, True),         # obs block only 2-byte aligned (byte-store path)
 ])
-@pytest.mark.parametrize("fused", [0, 1])
-def test_batch_matches_oracle(name, n_envs, steps, log_metrics, fused, monkeypatch):
-    """``fused``: ctf_step_observe as the two launches (k_step, k_observe) or as the single k_step_observe launch (forced:
-    at these batch sizes the library would choose the two launches by itself)."""
-    monkeypatch.setenv("CTF_FUSED", str(fused))
+def test_batch_matches_oracle(name, n_envs, steps, log_metrics):
     case = Case(name)
     auto_reset = name == "arena_stress"
     seeds = np.arange(n_envs, dtype=np.uint64) * 977 + 5
     vec = pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=log_metrics, **case.kwargs)
-    aligned16 = (case.n * case.c * case.g * case.g) % 16 == 0  # the fused kernel takes 16-byte aligned observation blocks only
-    assert vec.step_observe_launches() == (1 if fused and aligned16 else 2)
     cfg, _ = case.config(log_metrics=log_metrics)
     refs = [oracle.OracleEnv(cfg) for _ in range(n_envs)]
     for e, r in enumerate(refs):
@@ -224,7 +218,6 @@ def test_bench_variant_at_bench_size_over_an_episode_end_and_a_visitation_fold(w
     seeds = np.arange(E, dtype=np.uint64) + 2_000_006
     vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=True, **kw)
     n, g = vec.N_AGENTS, vec.GRID_SIZE
-    assert vec.step_observe_launches() == 1  # what bench.py times at this size: the fused k_step_observe<metrics>
     cfg, _ = pkg.config.build_config(kw, log_metrics=True)
     sample = np.unique(np.concatenate([np.linspace(0, E - 1, 61).astype(int), [1, 63, 64]]))
     sidx = torch.from_numpy(sample).to(vec.device)

@@ -14,9 +14,16 @@ os.makedirs(OUT, exist_ok=True)
 E = int(os.environ.get("AB_ENVS", 65536))
 kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
 vecs = []
+ENVS = {}  # variant -> environment variables set around its calls ("%VAR=VAL %VAR2=VAL2 <flags>")
 for i, flags in enumerate(sys.argv[1:]):
     so = os.path.join(OUT, f"lib{i}.so")
     src = CS
+    full = flags
+    ENVS[full] = {}
+    while flags.startswith("%"):
+        tok, _, flags = flags[1:].partition(" ")
+        k, _, v = tok.partition("=")
+        ENVS[full][k] = v
     if flags.startswith("@"):  # "@dir [flags]": build another copy of csrc (e.g. tools/_prev_csrc = the previous commit)
         src, _, flags_only = flags[1:].partition(" ")
         src = os.path.join(ROOT, src)
@@ -25,7 +32,7 @@ for i, flags in enumerate(sys.argv[1:]):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic",
                            "-I" + os.path.join(ROOT, "marl-ctf-development_amd", "csrc")]
                           + flags_only.split() + ["-shared", "-o", so, os.path.join(src, "ctf_abi.hip"), os.path.join(src, "ctf_kernels.hip")])
-    vecs.append((flags, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_", "ctf_step_observe_launches")), **kw)))
+    vecs.append((full, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_",)), **kw)))
 shared_obs, shared_meta = vecs[0][1].obs, vecs[0][1].meta
 acts = torch.zeros((E, 8), dtype=torch.int8, device="cuda")
 vecs[0][1].random_actions(acts, seed=5, step=0)
@@ -37,6 +44,7 @@ res = {f: ([], [], []) for f, _ in vecs}
 os.environ["CTF_FUSED"] = os.environ.get("AB_FUSED", "1")  # step_observe below: the single launch where the build has one
 for rnd in range(4):
     for flags, v in vecs:
+        os.environ.update(ENVS[flags])
         v.obs, v.meta = shared_obs, shared_meta
         for _ in range(10):
             v.step(acts, auto_reset=True); v.observe()
@@ -47,6 +55,8 @@ for rnd in range(4):
         for a, b in ev2:
             a.record(); v.step_observe(acts, auto_reset=True); b.record()
         torch.cuda.synchronize()
+        for k in ENVS[flags]:
+            del os.environ[k]
         if rnd:
             res[flags][0].append(np.median([a.elapsed_time(b) for a, b, c in ev]))
             res[flags][1].append(np.median([b.elapsed_time(c) for a, b, c in ev]))
