@@ -128,9 +128,15 @@ class BatchedRolloutCollector:
         mapped = self.rev_lut[env_act.long()]
         return trained, torch.where(self.is_team1[None, :], mapped, env_act).contiguous()
 
-    def collect(self, agent, opponent, reset=True):
+    def collect(self, agent, opponent, reset=True, handoff=None, handoff_chunk=16):
         """-> dict with the tensors ``get_single_rollout`` returns, each with an env axis after the slot axis.  In compact
-        mode ``grid_codes`` / ``next_grid_codes`` stand in for ``grid_states`` / ``next_grid_state``."""
+        mode ``grid_codes`` / ``next_grid_codes`` stand in for ``grid_states`` / ``next_grid_state``.
+
+        ``handoff``: a ``sharding.RolloutHandoff`` — the N > 1 path for a centralised learner.  Every ``handoff_chunk`` env
+        steps the chunk's compact slots (reward, log-prob, value, action, mask; with ``with_observations`` also codes and
+        metadata) are all-gathered asynchronously while the next steps run; the returned dict then carries under
+        ``"global"`` the same tensors for ALL ranks' envs in global env order ([S, world * E, ...]) plus the gathered
+        ``next_*`` tensors.  Compact mode only (the one-hot planes are 14x the bytes; a learner expands codes per minibatch)."""
         torch, vec, A = self.torch, self.vec, self.A
         use_codes = self.use_codes(agent, opponent)
         E, S, g = vec.n_envs, self.T * self.A, vec.GRID_SIZE
@@ -138,6 +144,13 @@ class BatchedRolloutCollector:
             self.grid_codes = torch.zeros((S, E, g, g), dtype=torch.uint8, device=vec.device)
         if not use_codes and self.grid_states is None:
             self.grid_states = torch.zeros((S, E, vec.N_CHANNELS, g, g), dtype=self.obs_dtype, device=vec.device)
+        if handoff is not None and handoff.with_observations and not use_codes:
+            raise ValueError("the rollout hand-off carries observations in compact form only (use policies with act_from_codes)")
+        local = dict(rewards=self.rewards, logprobs=self.logprobs, values=self.values, actions=self.actions,
+                     use_action_mask=self.use_action_mask, metadata_states=self.metadata_states)
+        if use_codes:
+            local["grid_codes"] = self.grid_codes
+        sent = 0
         if reset:
             vec.reset()  # ppo.py:57
         self.dones.zero_()
@@ -157,6 +170,9 @@ class BatchedRolloutCollector:
                 self.logprobs[sl] = a_lp
                 rewards, done = vec.step(env_act)
                 self.rewards[sl] = rewards.index_select(1, self.trained_idx).transpose(0, 1)
+                if handoff is not None and ((t + 1) % handoff_chunk == 0 or t + 1 == self.T):
+                    handoff.launch(sent, (t + 1) * A, local)  # async: runs beside the next steps
+                    sent = (t + 1) * A
             first = self.trained[0]
             if use_codes:
                 codes, meta = vec.observe_codes()
@@ -167,6 +183,15 @@ class BatchedRolloutCollector:
             next_meta = meta[:, first].to(torch.float32)
             next_done = done.to(torch.float32)
         grids = dict(grid_codes=self.grid_codes) if use_codes else dict(grid_states=self.grid_states)
-        return dict(metadata_states=self.metadata_states, actions=self.actions, use_action_mask=self.use_action_mask,
+        extra = {}
+        if handoff is not None:
+            glob = handoff.result()
+            glob["dones"] = torch.zeros_like(glob["rewards"])  # never written in the reference (ppo.py:53)
+            glob["next_done"] = handoff.gather_once(next_done)
+            if handoff.with_observations:
+                glob["next_metadata_state"] = handoff.gather_once(next_meta)
+                glob["next_grid_codes"] = handoff.gather_once(next_obs["next_grid_codes"])
+            extra["global"] = glob
+        return dict(**extra, metadata_states=self.metadata_states, actions=self.actions, use_action_mask=self.use_action_mask,
                     logprobs=self.logprobs, rewards=self.rewards, dones=self.dones, values=self.values,
                     next_metadata_state=next_meta, next_done=next_done, **grids, **next_obs)

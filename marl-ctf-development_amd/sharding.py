@@ -146,6 +146,96 @@ class ChunkedRolloutGather:
         return self.glob[b]
 
 
+class RolloutHandoff:
+    """All-gather of the COMPACT rollout a centralised PPO learner consumes (what ppo.py:46-55,74-84,105-109
+    stores per slot): reward f32, log-prob f32, value f32, action u8, use_action_mask u8 — and, optionally, the observation
+    the policy saw in compact form (grid codes u8 [G][G], metadata f16 [M]) — for the trained team's slots of every shard.
+
+    The collector hands over one CHUNK of slots at a time (``launch``), as soon as the chunk's last reward is stored; the
+    collectives (two per chunk: one float32 pack, one uint8 pack; two more with observations) run asynchronously beside the
+    following env steps.  ``result`` waits and returns tensors in GLOBAL env order: [S, world * E, ...] — rank-major, which
+    is the global env index because rank r owns envs [r * E, (r + 1) * E).  One rank (and no ``force_collective``): the
+    local tensors are returned as they are, nothing is copied."""
+
+    F32 = ("rewards", "logprobs", "values")
+    U8 = ("actions", "use_action_mask")
+
+    def __init__(self, world, group=None, with_observations=False, force_collective=False):
+        self.world, self.group = int(world), group
+        self.collective = world > 1 or force_collective
+        self.with_observations = bool(with_observations)
+        self.pending = []   # (slot range, {pack name: (work, gathered tensor)}, shapes)
+        self.local = None
+
+    def launch(self, lo, hi, local):
+        """local: dict name -> tensor [S, E, ...] of this rank (the collector's rollout buffers); slots [lo, hi) are final."""
+        import torch
+
+        self.local = local
+        if not self.collective or hi <= lo:
+            return
+        import torch.distributed as dist
+
+        packs = {
+            "f32": torch.stack([local[k][lo:hi].to(torch.float32) for k in self.F32], dim=1).contiguous(),     # [K, 3, E]
+            "u8": torch.stack([local[k][lo:hi].to(torch.uint8) for k in self.U8], dim=1).contiguous(),         # [K, 2, E]
+        }
+        if self.with_observations:
+            packs["codes"] = local["grid_codes"][lo:hi].contiguous()                                            # [K, E, G, G] u8
+            packs["meta"] = local["metadata_states"][lo:hi].to(torch.float16).contiguous()                      # [K, E, M] (f16 is exact: the env emits f16)
+        works = {}
+        for name, t in packs.items():
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            w = dist.all_gather_into_tensor(out.view((self.world * t.shape[0],) + tuple(t.shape[1:])), t, group=self.group, async_op=True)
+            works[name] = (w, out, t)  # (t is kept alive until the collective has read it)
+        self.pending.append(((lo, hi), works))
+
+    def result(self):
+        """-> dict name -> tensor [S, world * E, ...] over all launched chunks (slots not launched are not included: call
+        after the last ``launch``)."""
+        import torch
+
+        if not self.collective:
+            keys = self.F32 + self.U8 + (("grid_codes", "metadata_states") if self.with_observations else ())
+            return {k: self.local[k] for k in keys if k in self.local}
+        chunks = {}
+        for (lo, hi), works in self.pending:
+            for name, (w, out, _) in works.items():
+                w.wait()
+                chunks.setdefault(name, []).append(out)
+        self.pending = []
+
+        def glob(parts, env_dim):
+            # parts: [world, K, ..., E, ...] per chunk -> [sum K, ..., world * E, ...] with the rank axis merged into the env axis
+            t = torch.cat(parts, dim=1)
+            t = t.movedim(0, env_dim)  # [K, ..., world, E, ...]
+            shape = list(t.shape)
+            shape[env_dim:env_dim + 2] = [shape[env_dim] * shape[env_dim + 1]]
+            return t.reshape(shape)
+
+        f32 = glob(chunks["f32"], 2)  # [S, 3, world * E]
+        u8 = glob(chunks["u8"], 2)
+        out = {k: f32[:, i] for i, k in enumerate(self.F32)}
+        out.update({k: u8[:, i].to(torch.float32) for i, k in enumerate(self.U8)})  # the reference stores actions / masks as float32
+        if self.with_observations:
+            out["grid_codes"] = glob(chunks["codes"], 1)
+            out["metadata_states"] = glob(chunks["meta"], 1).to(torch.float32)
+        return out
+
+    def gather_once(self, t):
+        """Blocking all-gather of one [E, ...] tensor -> [world * E, ...] (the rollout's next_* tensors)."""
+        import torch
+
+        if not self.collective:
+            return t
+        import torch.distributed as dist
+
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+
 def max_over_ranks(value, device, world):
     """MAX over ranks of a python float (the timing rule of bench.py)."""
     if world == 1:

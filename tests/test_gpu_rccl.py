@@ -50,3 +50,49 @@ def test_rollout_gathers_over_rccl_with_one_rank():
         assert sh.max_over_ranks(1.5, dev, 2) == 1.5  # the all-reduce of the timing rule (forced through the collective)
     finally:
         dist.destroy_process_group()
+
+
+def test_collector_hands_the_full_compact_rollout_over_rccl():
+    """BatchedRolloutCollector(handoff=RolloutHandoff): the N > 1 path of BASELINE configs[3]/[4] as far as one GPU allows — a
+    one-rank RCCL group with the collectives forced on.  The gathered ("global") tensors must equal the local rollout, chunk
+    boundaries and the ragged last chunk included, with and without the observations."""
+    import importlib
+    import sys, os
+
+    import numpy as np
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _stub_policy import StubCodesPolicy
+
+    pkg = importlib.import_module("marl-ctf-development_amd")
+    rollout = importlib.import_module("marl-ctf-development_amd.rollout")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+        E, T = 96, 11
+        vec = pkg.VecGridworldCtf(E, device=0, py_seeds=np.arange(E) + 9, np_seeds=np.arange(E) + 9, **kw)
+        col = rollout.BatchedRolloutCollector(vec, T, 0)
+        a, b = StubCodesPolicy(4, vec.N_CHANNELS, pkg.expand_codes), StubCodesPolicy(6, vec.N_CHANNELS, pkg.expand_codes)
+        for with_obs in (False, True):
+            ho = sh.RolloutHandoff(1, with_observations=with_obs, force_collective=True)
+            out = col.collect(a, b, handoff=ho, handoff_chunk=4)  # chunks of 4, 4 and 3 env steps
+            g = out["global"]
+            for key in ("rewards", "logprobs", "values", "actions", "use_action_mask", "dones"):
+                assert g[key].shape == out[key].shape == (T * 4, E) and torch.equal(g[key], out[key]), key
+            assert torch.equal(g["next_done"], out["next_done"])
+            if with_obs:
+                assert torch.equal(g["grid_codes"], out["grid_codes"]) and torch.equal(g["metadata_states"], out["metadata_states"])
+                assert torch.equal(g["next_grid_codes"], out["next_grid_codes"]) and torch.equal(g["next_metadata_state"], out["next_metadata_state"])
+            else:
+                assert "grid_codes" not in g
+        # without a hand-off nothing changes
+        assert "global" not in col.collect(a, b)
+        vec.close()
+    finally:
+        dist.destroy_process_group()

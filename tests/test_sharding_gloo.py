@@ -74,6 +74,35 @@ def _worker(rank, world, port, q):
             want_r = torch.arange(0, world * E, dtype=torch.float32)[:, None].repeat(1, N) * 10 + t
             want_d = ((torch.arange(0, world * E) + t) % 3 == 0).to(torch.uint8)
             assert torch.equal(gr[:, t % 4].reshape(world * E, N), want_r) and torch.equal(gd[:, t % 4].reshape(world * E), want_d)
+        # the collector's hand-off of the FULL compact set (reward, log-prob, value, action, mask + codes / metadata),
+        # launched in chunks of slots as a rollout fills, returned in global env order
+        S, G, M = 12, 3, 5
+        env_ids = torch.arange(lo, hi, dtype=torch.float32)
+
+        def slot_major(scale, dtype=torch.float32):  # value of slot s, global env g = scale * (100 * s + g)
+            return (scale * (100.0 * torch.arange(S, dtype=torch.float32)[:, None] + env_ids[None, :])).to(dtype)
+
+        local = dict(rewards=slot_major(1.0), logprobs=slot_major(-0.5), values=slot_major(0.25),
+                     actions=(slot_major(1.0) % 9), use_action_mask=(slot_major(1.0) % 2),
+                     grid_codes=(slot_major(1.0) % 251).to(torch.uint8)[:, :, None, None].repeat(1, 1, G, G),
+                     metadata_states=slot_major(0.5)[:, :, None].repeat(1, 1, M))
+        for with_obs in (False, True):
+            ho = sh.RolloutHandoff(world, with_observations=with_obs)
+            for a, b in ((0, 4), (4, 8), (8, 12)):
+                ho.launch(a, b, local)
+            got = ho.result()
+            all_ids = torch.arange(0, world * E, dtype=torch.float32)
+            full = 100.0 * torch.arange(S, dtype=torch.float32)[:, None] + all_ids[None, :]
+            assert torch.equal(got["rewards"], full) and torch.equal(got["logprobs"], -0.5 * full) and torch.equal(got["values"], 0.25 * full)
+            assert torch.equal(got["actions"], full % 9) and torch.equal(got["use_action_mask"], full % 2)
+            assert got["actions"].dtype == torch.float32 and got["rewards"].shape == (S, world * E)
+            if with_obs:
+                assert torch.equal(got["grid_codes"], (full % 251).to(torch.uint8)[:, :, None, None].repeat(1, 1, G, G))
+                assert torch.equal(got["metadata_states"], (0.5 * full)[:, :, None].repeat(1, 1, M))
+            else:
+                assert "grid_codes" not in got
+            nd = ho.gather_once((env_ids % 2).clone())
+            assert torch.equal(nd, all_ids % 2)
         slow = sh.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
         assert slow == float(world)
         q.put((rank, "ok"))
