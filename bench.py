@@ -332,6 +332,12 @@ def main():
                     "kernels_ms": {"k_step": r2["k_step_ms"], r2["observe_kernel"]: r2["k_observe_ms"]},
                     "placement_probe_ms": r2["placement_probe_ms"], "device_status_bits": r2["status"],
                 }
+            try:  # BASELINE configs[4] on one GPU: self-play rollout (env + two policy networks) + the reference's PPO update
+                import bench_rollout
+
+                sec["ppo_selfplay_16384x16"] = bench_rollout.run(envs=16384, steps=16, device=local_rank)
+            except Exception as exc:  # a secondary must never cost the headline line
+                sec["ppo_selfplay_16384x16"] = {"error": repr(exc)}
             line["secondary"] = sec
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, r["kwargs"])
