@@ -150,6 +150,13 @@ int ctf_seed(ctf_env* env, const uint64_t* py_seeds, const uint64_t* np_seeds, v
 int ctf_set_rng_state(ctf_env* env, int32_t env_index, const uint32_t* py_mt625, const uint32_t* np_mt625);
 int ctf_get_rng_state(ctf_env* env, int32_t env_index, uint32_t* py_mt625, uint32_t* np_mt625);
 
+/* The same for ALL envs at once, stream-ordered and without a device synchronisation: py_dev / np_dev are DEVICE arrays
+ * uint32 [E][625] (624 state words + position per env, either may be NULL).  ctf_get_rng_states returns the standard
+ * form (a lazily regenerated block is finished on the device).  What the facade's global-RNG contract uses per step
+ * (random.getstate() / np.random.get_state() in, the advanced states out) and what a checkpoint of a batch needs. */
+int ctf_set_rng_states(ctf_env* env, const uint32_t* py_dev, const uint32_t* np_dev, void* stream);
+int ctf_get_rng_states(ctf_env* env, uint32_t* py_dev, uint32_t* np_dev, void* stream);
+
 /* GridworldCtf.reset() (gridworld_ctf.py:383-477) for the envs whose mask byte is non-zero
  * (NULL = all).  Draws no random numbers and keeps `_arr`, like the reference. */
 int ctf_reset(ctf_env* env, const uint8_t* env_mask_dev, void* stream);

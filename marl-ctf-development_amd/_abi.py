@@ -113,6 +113,8 @@ SYMBOLS = {
     "ctf_seed": (C.c_int, [_P, _P, _P, _P]),
     "ctf_set_rng_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ctf_get_rng_state": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ctf_set_rng_states": (C.c_int, [_P, _P, _P, _P]),
+    "ctf_get_rng_states": (C.c_int, [_P, _P, _P, _P]),
     "ctf_reset": (C.c_int, [_P, _P, _P]),
     "ctf_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_observe": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),

@@ -20,6 +20,8 @@ extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t ctf_launch_import_rng(const DevCfg&, const DevPtrs&, const uint32_t*, const uint32_t*, hipStream_t);
+extern "C" hipError_t ctf_launch_export_rng(const DevCfg&, const DevPtrs&, uint32_t*, uint32_t*, hipStream_t);
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
 
 struct ctf_env {
@@ -330,6 +332,22 @@ extern "C" int ctf_get_rng_state(ctf_env* h, int32_t e, uint32_t* py, uint32_t* 
         if (packed & CTF_LAZY_BIT) finish_block(dst[k], pos);
         dst[k][CTF_MT_N] = pos;
     }
+    return CTF_OK;
+}
+
+extern "C" int ctf_set_rng_states(ctf_env* h, const uint32_t* py_dev, const uint32_t* np_dev, void* stream) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (!py_dev && !np_dev) return CTF_OK;
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_import_rng(h->d, h->p, py_dev, np_dev, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+extern "C" int ctf_get_rng_states(ctf_env* h, uint32_t* py_dev, uint32_t* np_dev, void* stream) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (!py_dev && !np_dev) return CTF_OK;
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_export_rng(h->d, h->p, py_dev, np_dev, (hipStream_t)stream));
     return CTF_OK;
 }
 

@@ -1213,6 +1213,61 @@ extern "C" __global__ void k_export_counters(DevCfg cfg, DevPtrs p, int32_t* met
 }
 
 // ------------------------------------------------------------------------------------------------
+// bulk hand-over of the twin MT19937 states, stream-ordered (the facade's global-RNG contract; checkpoints)
+// ------------------------------------------------------------------------------------------------
+// Standard form per env and generator: 624 state words + the position (0..624), as random.getstate()[1] /
+// np.random.get_state()[1:3] give them.  One block per env.
+extern "C" __global__ void __launch_bounds__(256) k_import_rng(DevCfg cfg, DevPtrs p, const uint32_t* __restrict__ py,
+                                                               const uint32_t* __restrict__ np_) {
+    const int e = blockIdx.x;
+    const uint32_t* src[2] = {py, np_};
+    uint32_t* dst[2] = {p.mt_py, p.mt_np};
+    for (int k = 0; k < 2; k++) {
+        if (!src[k]) continue;
+        const uint32_t* in = src[k] + (size_t)e * (CTF_MT_N + 1);
+        uint32_t* out = dst[k] + (size_t)e * CTF_MT_N;
+        for (int i = threadIdx.x; i < CTF_MT_N; i += blockDim.x) out[i] = in[i];
+        // lazy flag clear: words [pos, 624) are output as they stand
+        if (threadIdx.x == 0) p.rngpos[2 * e + k] = in[CTF_MT_N] > CTF_MT_N ? CTF_MT_N : in[CTF_MT_N];
+    }
+}
+// A lazily regenerated block ([0, pos) new, [pos, 624) old) is finished first: word i needs the OLD a[i], a[i + 1] and
+// a[i + 397] for i < 227, the NEW a[i - 227] beyond — chunks of 227 words, every chunk read completely before it is written.
+extern "C" __global__ void __launch_bounds__(256) k_export_rng(DevCfg cfg, DevPtrs p, uint32_t* __restrict__ py, uint32_t* __restrict__ np_) {
+    __shared__ uint32_t a[CTF_MT_N];
+    const int e = blockIdx.x, t = threadIdx.x;
+    uint32_t* dst[2] = {py, np_};
+    const uint32_t* src[2] = {p.mt_py, p.mt_np};
+    for (int k = 0; k < 2; k++) {
+        if (!dst[k]) continue;  // uniform
+        const uint32_t packed = p.rngpos[2 * e + k];
+        const int pos = (int)(packed & CTF_POS_MASK);
+        for (int i = t; i < CTF_MT_N; i += blockDim.x) a[i] = src[k][(size_t)e * CTF_MT_N + i];
+        __syncthreads();
+        if (packed & CTF_LAZY_BIT) {
+            for (int c = pos; c < CTF_MT_N; c += 227) {
+                const int i = c + t;
+                const bool on = t < 227 && i < CTF_MT_N;
+                uint32_t v = 0;
+                if (on) {
+                    const uint32_t x0 = a[i], x1 = a[i + 1 == CTF_MT_N ? 0 : i + 1];
+                    const uint32_t m = a[i + 397 >= CTF_MT_N ? i + 397 - CTF_MT_N : i + 397];
+                    const uint32_t y = (x0 & 0x80000000u) | (x1 & 0x7fffffffu);
+                    v = m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+                __syncthreads();
+                if (on) a[i] = v;
+                __syncthreads();
+            }
+        }
+        uint32_t* out = dst[k] + (size_t)e * (CTF_MT_N + 1);
+        for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = a[i];
+        if (t == 0) out[CTF_MT_N] = (uint32_t)pos;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic actions: Philox4x32-10 (Salmon et al. 2011), one lane per (env, block of 8 agents)
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void k_random_actions(DevCfg cfg, int8_t* actions, uint64_t seed, uint32_t step, uint32_t env_offset) {
@@ -1329,6 +1384,14 @@ extern "C" hipError_t ctf_launch_export_counters(const DevCfg& cfg, const DevPtr
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_export_counters, dim3(blocks), dim3(256), 0, st, cfg, p, metrics, captures, steps);
+    return hipGetLastError();
+}
+extern "C" hipError_t ctf_launch_import_rng(const DevCfg& cfg, const DevPtrs& p, const uint32_t* py, const uint32_t* np_, hipStream_t st) {
+    hipLaunchKernelGGL(k_import_rng, dim3(cfg.n_envs), dim3(256), 0, st, cfg, p, py, np_);
+    return hipGetLastError();
+}
+extern "C" hipError_t ctf_launch_export_rng(const DevCfg& cfg, const DevPtrs& p, uint32_t* py, uint32_t* np_, hipStream_t st) {
+    hipLaunchKernelGGL(k_export_rng, dim3(cfg.n_envs), dim3(256), 0, st, cfg, p, py, np_);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg& cfg, int8_t* actions, uint64_t seed, uint32_t step,

@@ -196,6 +196,22 @@ class VecGridworldCtf:
         _abi.check(self._lib.ctf_get_rng_state(self._h, env_index, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), self._lib)
         return a, b
 
+    def set_rng_states(self, py_states=None, np_states=None):
+        """Bulk, stream-ordered hand-over: uint32 CUDA tensors [E, 625] (624 words + position per env), either may be None."""
+        torch = _torch()
+        ptr = lambda t: None if t is None else self._check_dev(t, torch.int32 if t.dtype == torch.int32 else torch.uint32, self.n_envs * 625)
+        _abi.check(self._lib.ctf_set_rng_states(self._h, ptr(py_states), ptr(np_states), self._stream()), self._lib)
+
+    def get_rng_states(self, py=True, np_=True):
+        """-> (py_states, np_states): int32 CUDA tensors [E, 625] holding the uint32 words of both generators of every env in
+        the standard form (None for a generator not asked for).  Stream-ordered; no device synchronisation."""
+        torch = _torch()
+        a = torch.empty((self.n_envs, 625), dtype=torch.int32, device=self.device) if py else None
+        b = torch.empty((self.n_envs, 625), dtype=torch.int32, device=self.device) if np_ else None
+        _abi.check(self._lib.ctf_get_rng_states(self._h, None if a is None else C.c_void_p(a.data_ptr()),
+                                                None if b is None else C.c_void_p(b.data_ptr()), self._stream()), self._lib)
+        return a, b
+
     # -- the hot path -------------------------------------------------------------------------
     def reset(self, mask=None):
         ptr = None if mask is None else self._check_dev(mask, _torch().uint8, self.n_envs)
@@ -433,16 +449,23 @@ class GridworldCtf:
             assert np.all(self.standardise_state(0) == self.standardise_state(1, reverse_grid=True))
 
     def _push_global_rng(self):
-        py = np.array(_py_random.getstate()[1], dtype=np.uint32)
+        """random / np.random -> the device streams of env 0: one host array, one upload, one stream-ordered launch (no
+        device synchronisation, no per-word copies)."""
+        torch = _torch()
         st = np.random.get_state()
-        npw = np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)])
-        self._vec.set_rng_state(0, py, npw)
+        both = np.empty((2, 625), dtype=np.uint32)
+        both[0] = _py_random.getstate()[1]
+        both[1, :624] = st[1]
+        both[1, 624] = st[2]
+        dev = torch.from_numpy(both.view(np.int32)).to(self._vec.device)
+        self._vec.set_rng_states(dev[0:1], dev[1:2])
         return st
 
     def _pull_global_rng(self, np_state_before):
-        py, npw = self._vec.get_rng_state(0)
-        _py_random.setstate((3, tuple(int(x) for x in py), None))
-        np.random.set_state((np_state_before[0], npw[:624].copy(), int(npw[624]), np_state_before[3], np_state_before[4]))
+        py, npw = self._vec.get_rng_states()
+        both = _torch().cat((py, npw)).cpu().numpy().view(np.uint32)  # the step's only synchronisation
+        _py_random.setstate((3, tuple(int(x) for x in both[0]), None))
+        np.random.set_state((np_state_before[0], both[1, :624].copy(), int(both[1, 624]), np_state_before[3], np_state_before[4]))
 
     def step(self, actions):
         torch = _torch()
@@ -512,3 +535,91 @@ class GridworldCtf:
         plt.imshow(self.grid, vmin=0, vmax=13, cmap="tab20")
         plt.title(f"step {self.env_step_count}")
         plt.pause(sleep_time)
+
+    @staticmethod
+    def render_indices(grid, agent_positions, has_flag, agent_teams, flag_positions):
+        """The sprite index of every cell as the reference's ``render_image`` chooses it (gridworld_ctf.py:1130-1154): the
+        tile code; 112 / 113 at a team's home flag cell while the OTHER team carries that flag; + 100 for an agent that
+        carries a flag.  Pure function of the host-side state (tested without a GPU)."""
+        idx = np.array(grid, dtype=np.int32)
+        teams_with_flag = {0: 0, 1: 0}
+        for a, flag in enumerate(has_flag):
+            if flag == 1:
+                teams_with_flag[agent_teams[a]] = 1
+        if teams_with_flag[1] == 1:
+            idx[tuple(flag_positions[0])] = 112
+        if teams_with_flag[0] == 1:
+            idx[tuple(flag_positions[1])] = 113
+        for a, pos in agent_positions.items():
+            if has_flag[a] == 1:
+                idx[tuple(pos)] += 100
+        return idx
+
+    # one colour per sprite index (the reference pastes PNG sprites from cwd/img; this build draws squares and letters, so
+    # that ``utils.create_gif`` / ``duel(render=True)`` work without those files)
+    _SPRITE_RGB = {0: (0.93, 0.93, 0.93), 1: (0.25, 0.25, 0.25), 2: (0.55, 0.45, 0.35), 3: (0.72, 0.62, 0.52),
+                   12: (0.35, 0.55, 1.0), 13: (1.0, 0.4, 0.4), 112: (0.8, 0.85, 1.0), 113: (1.0, 0.85, 0.85)}
+    _TYPE_LETTER = "SGVM"  # scout, guardian, vaulter, miner
+
+    def render_image(self, frame_path=None, plot_image=False):
+        """gridworld_ctf.py:1112-1163: one image of the current grid; saved to ``frame_path`` (dpi 300, then closed) and / or
+        shown.  Same cell -> sprite choice as the reference (``render_indices``); drawn with matplotlib primitives."""
+        import matplotlib.pyplot as plt
+
+        idx = self.render_indices(self.grid, self.agent_positions, self.has_flag, self.AGENT_TEAMS, self.FLAG_POSITIONS)
+        g = self.GRID_SIZE
+        rgb = np.zeros((g, g, 3))
+        fig, ax = plt.subplots(figsize=(5, 5))
+        for i in range(g):
+            for j in range(g):
+                k = int(idx[i, j])
+                base = k - 100 if (k >= 104 and k <= 111) else k
+                if 4 <= base <= 11:  # an agent: team colour, type letter, a ring when it carries a flag
+                    team = 0 if base < 8 else 1
+                    rgb[i, j] = (0.2, 0.4, 0.9) if team == 0 else (0.9, 0.25, 0.25)
+                    ax.text(j, i, self._TYPE_LETTER[(base - 4) % 4] + ("*" if k >= 100 else ""), ha="center", va="center",
+                            color="white", fontsize=max(4, 110 // g), fontweight="bold")
+                else:
+                    rgb[i, j] = self._SPRITE_RGB.get(k, (1.0, 0.0, 1.0))
+                    if k in (12, 13, 112, 113):
+                        ax.text(j, i, "F" if k < 100 else "f", ha="center", va="center", color="black", fontsize=max(4, 110 // g))
+        ax.imshow(rgb, interpolation="nearest")
+        ax.set_xticks(np.arange(-0.5, g, 1))
+        ax.set_yticks(np.arange(-0.5, g, 1))
+        ax.set_xticklabels([])
+        ax.set_yticklabels([])
+        ax.grid(color="white", linewidth=1)
+        ax.tick_params(length=0)
+        if plot_image:
+            plt.show()
+        if frame_path is not None:
+            fig.savefig(frame_path, dpi=300)
+            plt.close(fig)
+
+    def play(self, player=0, agents=None, use_ego_state=False, device="cpu", render_ego_state=False):
+        """gridworld_ctf.py:1165-1262: step the env from the keyboard (w s d a x = actions 0..4, t g h f = 5..8, p = quit);
+        the other agents act randomly through ``np.random.randint(8, size=N)`` as in the reference.  ``agents`` (the
+        reference's path through ``choose_action`` / ``ut.add_noise``, which its own networks do not provide) is not supported."""
+        if agents is not None:
+            raise NotImplementedError("play(agents=...) relies on Agent.choose_action, which the reference's networks do not define")
+        keys = {"w": 0, "s": 1, "d": 2, "a": 3, "x": 4, "t": 5, "g": 6, "h": 7, "f": 8}
+        self.reset()
+        self.render()
+        move_counter, total_score = 0, 0
+        while True:
+            print(f"Move {move_counter}")
+            raw = None
+            while raw not in list(keys) + ["p"]:
+                raw = input("Enter an action")
+            if raw == "p":
+                print("Game exited")
+                break
+            actions = np.random.randint(8, size=self.N_AGENTS)
+            actions[player] = keys[raw]
+            _, rewards, done = self.step([int(a) for a in actions])
+            total_score += rewards[0]
+            move_counter += 1
+            self.render()
+            if done:
+                print(f"You win!, total score {total_score}")
+                break

@@ -333,6 +333,45 @@ def test_reset_mask_and_state_roundtrip():
     vec.close()
 
 
+def test_bulk_rng_hand_over_equals_the_per_env_one():
+    """ctf_get_rng_states / ctf_set_rng_states ([E][625], stream-ordered) against the per-env synchronous calls: states
+    mid-block (lazily regenerated on the device, finished by the export kernel) and freshly seeded ones; a state set in
+    bulk continues exactly like the env it came from."""
+    case = Case("arena_random")
+    E = 300
+    seeds = np.arange(E, dtype=np.uint64) * 31 + 7
+    vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=seeds, np_seeds=seeds, **case.kwargs)
+    acts = torch.empty((E, case.n), dtype=torch.int8, device=vec.device)
+    for t in range(23):  # ~64 np words and ~14 py words per step: several block boundaries are crossed, at different points per env
+        if t in (0, 7, 22):
+            py, npw = (x.cpu().numpy().view(np.uint32) for x in vec.get_rng_states())
+            for e in (0, 1, 63, 64, 150, E - 1):
+                one_py, one_np = vec.get_rng_state(e)
+                assert np.array_equal(py[e], one_py) and np.array_equal(npw[e], one_np), (t, e)
+        vec.random_actions(acts, seed=11, step=t)
+        vec.step(acts)
+    # twin batch: states handed over in bulk, same actions from here on -> identical trajectories
+    twin = pkg.VecGridworldCtf(E, device=_dev(), **case.kwargs)
+    py_d, np_d = vec.get_rng_states()
+    twin.set_rng_states(py_d, np_d)
+    for e in (0, 64, E - 1):
+        twin.set_state(e, vec.get_state(e))
+    for t in range(23, 40):
+        vec.random_actions(acts, seed=11, step=t)
+        vec.step(acts, want_f64=True)
+        twin.step(acts, want_f64=True)
+        for e in (0, 64, E - 1):
+            assert torch.equal(vec.rewards64[e], twin.rewards64[e]), (t, e)
+    for e in (0, 64, E - 1):
+        _state_equal(view_arrays(twin.get_state(e), case.n, case.g), view_arrays(vec.get_state(e), case.n, case.g), f"twin env {e}")
+        a, b = vec.get_rng_state(e), twin.get_rng_state(e)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    only_np = twin.get_rng_states(py=False)
+    assert only_np[0] is None and only_np[1].shape == (E, 625)
+    vec.close()
+    twin.close()
+
+
 def test_status_bits_for_bad_action_and_action_mask():
     case = Case("split_random")
     vec = pkg.VecGridworldCtf(4, device=_dev(), **case.kwargs)
