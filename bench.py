@@ -67,6 +67,18 @@ WORKLOADS = {
 }
 
 
+def _host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+
+
 def cpu_baseline(pkg, kwargs, budget_s=12.0):
     """The CPU oracle (kind "port": the C restatement pinned to the reference by tests/golden) timed on this
     box's host cores on a bounded sample of the same workload: batches of arena envs x 200 steps of
@@ -93,6 +105,7 @@ def cpu_baseline(pkg, kwargs, budget_s=12.0):
         "kind": "port",
         "sample": f"{done_envs} envs x {steps} steps, 8_arena step()+observe(), C oracle, OpenMP over envs ({dt:.1f} s)",
         "single_core_value": one,
+        "host_cpu": _host_cpu(),
     }
     try:  # the per-env Python/NumPy restatement on one core: calibrates this box against BASELINE.md's 1.2 k env-steps/s
         from oracle import ctf_numpy
