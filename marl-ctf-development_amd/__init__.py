@@ -20,7 +20,7 @@ from .duel import batched_duel  # noqa: F401
 
 
 def __getattr__(name):  # the policy module needs torch.nn: import it only when asked for
-    if name in ("policy", "policy_native"):
+    if name in ("policy", "policy_native", "learner"):
         import importlib
 
         return importlib.import_module(__name__ + "." + name)
