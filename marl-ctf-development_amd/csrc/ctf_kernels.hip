@@ -202,7 +202,7 @@ __device__ __forceinline__ double sel4(const double* t, int k) {
 #endif
 // Profiling-only ablations of the step kernel (results become wrong; never defined in the shipped build):
 //   bit0 no tagging, bit1 no metric section, bit2 no shuffles, bit3 no act, bit4 no visitation atomics,
-//   bit5 no metric flush, bit6 no state write-back
+//   bit5 no metric flush, bit6 no state write-back, bit7 MT refills without their loads, bit8 MT flushes without their stores
 #ifndef STEP_ABLATE
 #define STEP_ABLATE 0
 #endif
@@ -232,68 +232,148 @@ __device__ __forceinline__ MtWin mtw_open(uint32_t* base, uint32_t* win, uint32_
     g.n = 0; g.cur = 0;
     return g;
 }
-// write the consumed, regenerated words back (one word per sub-lane per pass) and advance; unconsumed window words
-// are simply dropped — they are recomputed from unchanged state words by the next refill
+// ---- the window's traffic with the state array.  Sub-lane j of the group owns the T = WCAP / W CONSECUTIVE window words
+// [T j, T j + T): its state words are one (4-byte aligned) multi-dword access, so that a group reads / writes whole 64-byte
+// runs instead of 16-byte pieces — the MT streams are 40 % of the step kernel's time, all of it memory requests.
+typedef uint32_t mt_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t mt_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+// words a[i0 .. i0 + T) with indices taken modulo 624 (i0 < 624)
+template <int T>
+__device__ __forceinline__ void mt_load_span(const uint32_t* a, uint32_t i0, uint32_t* out) {
+    if (i0 + T <= CTF_MT_N) {
+        if constexpr (T % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < T / 4; q++) {
+                const mt_u32x4 v = *(const mt_u32x4*)(a + i0 + 4 * q);
+                out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+            }
+        } else if constexpr (T == 2) {
+            const mt_u32x2 v = *(const mt_u32x2*)(a + i0);
+            out[0] = v.x; out[1] = v.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < T; k++) out[k] = a[i0 + k];
+        }
+    } else {  // the span crosses the end of the block
+#pragma unroll
+        for (int k = 0; k < T; k++) out[k] = a[i0 + k >= CTF_MT_N ? i0 + k - CTF_MT_N : i0 + k];
+    }
+}
+// stores the consumed, regenerated words of the window (words [0, cur)) back to the state array
+template <int W>
+__device__ __forceinline__ void mtw_store_consumed(const MtWin& g, int j) {
+    constexpr int T = WCAP / W;
+    if (STEP_ABLATE & 256) return;  // no flush stores
+    const int c = (int)g.cur - T * j;  // how many of this lane's words were consumed
+    if (c <= 0) return;
+    const uint32_t idx0 = g.pos + (uint32_t)(T * j);
+    const bool crossing = idx0 < CTF_MT_N && idx0 + T > CTF_MT_N;
+    if (T % 4 == 0 && c >= T && !crossing && (g.lazy || idx0 >= CTF_MT_N)) {
+        uint32_t* dst = g.a + (idx0 >= CTF_MT_N ? idx0 - CTF_MT_N : idx0);
+#pragma unroll
+        for (int q = 0; q < T / 4; q++) {
+            const mt_u32x4 v = {g.win[T * j + 4 * q], g.win[T * j + 4 * q + 1], g.win[T * j + 4 * q + 2], g.win[T * j + 4 * q + 3]};
+            *(mt_u32x4*)(dst + 4 * q) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < T; k++) {
+        const uint32_t idx = idx0 + (uint32_t)k;
+        const bool wrapped = idx >= CTF_MT_N;
+        if (k < c && (g.lazy | (uint32_t)wrapped)) g.a[wrapped ? idx - CTF_MT_N : idx] = g.win[T * j + k];
+    }
+}
+// write the consumed words back and advance; unconsumed window words are simply dropped — they are recomputed from
+// unchanged state words by the next refill
 template <int W>
 __device__ __forceinline__ void mtw_flush(MtWin& g, int j) {
-    for (uint32_t jj = (uint32_t)j; jj < g.cur; jj += W) {
-        const uint32_t idx = g.pos + jj;
-        const bool wrapped = idx >= CTF_MT_N;
-        if (g.lazy | (uint32_t)wrapped) g.a[wrapped ? idx - CTF_MT_N : idx] = g.win[jj];
-    }
+    mtw_store_consumed<W>(g, j);
     g.pos += g.cur;
     if (g.pos > CTF_MT_N) { g.pos -= CTF_MT_N; g.lazy = 1; }
     g.n = 0; g.cur = 0;
 }
+// flush + refill in one: the NEW window's loads are issued first, then the consumed words of the old window are stored, then
+// the new window is written.  The words loaded are never among the words stored: the loads touch [npos, npos + WCAP], their
+// + 397 partners and, beyond 227, words regenerated >= 211 positions ago; the stores [npos - cur, npos).
 template <int W>
-__device__ __forceinline__ void mtw_refill(MtWin& g, int j) {
+__device__ __forceinline__ void mtw_cycle(MtWin& g, int j, int gshift) {
     constexpr int T = WCAP / W;
-    uint32_t x0[T], x1[T], m[T];
-    bool lz[T];
+    uint32_t npos = g.pos + g.cur, nlazy = g.lazy;
+    if (npos > CTF_MT_N) { npos -= CTF_MT_N; nlazy = 1; }
+    const uint32_t idx0 = npos + (uint32_t)(T * j);                       // stream index of this lane's first word
+    const uint32_t i0 = idx0 >= CTF_MT_N ? idx0 - CTF_MT_N : idx0;        // ... as a state word
+    uint32_t x0[T], x1n, m[T];
+    if (STEP_ABLATE & 128) {  // no refill loads
 #pragma unroll
-    for (int t = 0; t < T; t++) {  // all loads first: one exposed memory latency per refill
-        const uint32_t idx = g.pos + (uint32_t)(j + t * W);
-        const bool wrapped = idx >= CTF_MT_N;
-        const uint32_t i = wrapped ? idx - CTF_MT_N : idx;
-        lz[t] = (g.lazy | (uint32_t)wrapped) != 0;
-        x0[t] = g.a[i];
-        x1[t] = g.a[i + 1 == CTF_MT_N ? 0u : i + 1];
-        m[t] = g.a[i + 397 >= CTF_MT_N ? i + 397 - CTF_MT_N : i + 397];
+        for (int k = 0; k < T; k++) { x0[k] = (i0 + k) * 2654435761u; m[k] = x0[k] >> 3; }
+        x1n = x0[0] ^ 0x55u;
+    } else {
+        mt_load_span<T>(g.a, i0, x0);
+        mt_load_span<T>(g.a, i0 + 397 >= CTF_MT_N ? i0 + 397 - CTF_MT_N : i0 + 397, m);
+        // a[i + 1] of the lane's last word = the next lane's first word; the group's last lane loads it
+        const uint32_t inext = i0 + T >= CTF_MT_N ? i0 + T - CTF_MT_N : i0 + T;
+        x1n = (j == W - 1) ? g.a[inext] : 0u;
+    }
+    mtw_store_consumed<W>(g, j);  // the old window's consumed, regenerated words go back (LDS reads -> global stores)
+    if (W > 1) {
+        const uint32_t from_next = (uint32_t)__shfl((int)x0[0], gshift + ((j + 1) & (W - 1)), WAVE);
+        if (j != W - 1) x1n = from_next;
     }
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-        const uint32_t y = (x0[t] & 0x80000000u) | (x1[t] & 0x7fffffffu);
-        const uint32_t v = m[t] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        g.win[j + t * W] = lz[t] ? v : x0[t];
+    for (int k = 0; k < T; k++) {
+        const uint32_t idx = idx0 + (uint32_t)k;
+        const bool lz = (nlazy | (uint32_t)(idx >= CTF_MT_N)) != 0;
+        const uint32_t nx = (k + 1 < T) ? x0[k + 1 < T ? k + 1 : 0] : x1n;
+        const uint32_t y = (x0[k] & 0x80000000u) | (nx & 0x7fffffffu);
+        const uint32_t v = m[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        g.win[T * j + k] = lz ? v : x0[k];
     }
+    g.pos = npos; g.lazy = nlazy;
     g.n = WCAP; g.cur = 0;
 }
 // make sure `need` (<= WCAP) words are in the window; group-uniform, so the W lanes refill together
 template <int W>
-__device__ __forceinline__ void mtw_ensure(MtWin& g, int j, uint32_t need) {
-    if (g.n - g.cur < need) { mtw_flush<W>(g, j); mtw_refill<W>(g, j); }
+__device__ __forceinline__ void mtw_ensure(MtWin& g, int j, int gshift, uint32_t need) {
+    if (g.n - g.cur < need) mtw_cycle<W>(g, j, gshift);
 }
 template <int W>
-__device__ __forceinline__ uint32_t mtw_next(MtWin& g, int j) {
-    mtw_ensure<W>(g, j, 1);
+__device__ __forceinline__ uint32_t mtw_next(MtWin& g, int j, int gshift) {
+    mtw_ensure<W>(g, j, gshift, 1);
     return mt_temper(g.win[g.cur++]);
 }
-// CPython random._randbelow_with_getrandbits(n): k = n.bit_length(); draw k bits until < n
+// CPython random._randbelow_with_getrandbits(n): k = n.bit_length(); draw k bits until < n.
+// The W lanes of the group look at the next W words of the stream at once (sub-lane q at word cur + q): the first accepted
+// one is the draw and everything up to it is consumed — the same words in the same order as the one-word-at-a-time loop, in
+// ~1.3 rounds instead of the ~5 that the slowest of a wave's 16 groups needs when the acceptance probability is 1/2.
 template <int W>
-__device__ __forceinline__ uint32_t py_randbelow(MtWin& g, int j, uint32_t n) {
+__device__ __forceinline__ uint32_t py_randbelow(MtWin& g, int j, int gshift, uint32_t n) {
     const uint32_t sh = (uint32_t)__clz((int)n);
-    uint32_t r;
-    do { r = mtw_next<W>(g, j) >> sh; } while (r >= n);
-    return r;
+    if (W == 1) {
+        uint32_t r;
+        do { r = mtw_next<W>(g, j, gshift) >> sh; } while (r >= n);
+        return r;
+    }
+    for (;;) {
+        mtw_ensure<W>(g, j, gshift, (uint32_t)W);
+        const uint32_t r = mt_temper(g.win[g.cur + j]) >> sh;
+        const uint32_t ok = (uint32_t)(__ballot(r < n) >> gshift) & ((1u << W) - 1u);
+        if (ok) {
+            const int first = __ffs((int)ok) - 1;
+            g.cur += (uint32_t)first + 1u;
+            return (uint32_t)__shfl((int)r, gshift + first, WAVE);
+        }
+        g.cur += W;
+    }
 }
 // NumPy legacy randint(k), k >= 1: masked rejection on one 32-bit word; k == 1 draws nothing
 template <int W>
-__device__ __forceinline__ uint32_t np_randint(MtWin& g, int j, uint32_t k) {
+__device__ __forceinline__ uint32_t np_randint(MtWin& g, int j, int gshift, uint32_t k) {
     const uint32_t rng = k - 1;
     if (rng == 0) return 0;
     const uint32_t mask = 0xFFFFFFFFu >> __clz((int)rng);
     uint32_t v;
-    do { v = mtw_next<W>(g, j) & mask; } while (v > rng);
+    do { v = mtw_next<W>(g, j, gshift) & mask; } while (v > rng);
     return v;
 }
 
@@ -340,7 +420,7 @@ __device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx<W>& s, 
         for (int c = c0; c < c1; c++)
             if (s.sg[r * G + c] == 0) { open |= 1u << ((r - r0) * 3 + (c - c0)); k++; }
     if (k == 0) { status |= CTF_ST_NO_RESPAWN; return; }
-    const uint32_t rnd = np_randint<W>(np_, s.j, (uint32_t)k);
+    const uint32_t rnd = np_randint<W>(np_, s.j, s.gshift, (uint32_t)k);
     uint32_t bits = open;
     for (uint32_t t = 0; t < rnd; t++) bits &= bits - 1;  // drop the rnd lowest candidates
     const int sel = __ffs((int)bits) - 1;
@@ -407,13 +487,10 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
     for (int phase = 0; phase < 2; phase++) {
         // top the CPython window up while the whole wave is at the same point (rejection sampling lets the groups'
         // stream positions diverge; refilling on demand would re-run the refill per group)
-        if (!(STEP_ABLATE & 4)) {
-        mtw_flush<W>(py, j);
-        mtw_refill<W>(py, j);
-        }
+        if (!(STEP_ABLATE & 4)) mtw_cycle<W>(py, j, s.gshift);
 #pragma unroll 1
         for (int i = (STEP_ABLATE & 4) ? 0 : N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
-            const uint32_t r = py_randbelow<W>(py, j, (uint32_t)i + 1u);
+            const uint32_t r = py_randbelow<W>(py, j, s.gshift, (uint32_t)i + 1u);
             const uint64_t vi = (perm >> (4 * i)) & 15u, vr = (perm >> (4 * r)) & 15u;
             perm = (perm & ~((uint64_t)15u << (4 * i)) & ~((uint64_t)15u << (4 * r))) | (vr << (4 * i)) | (vi << (4 * r));
         }
@@ -506,7 +583,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
                 while (q0 < no) {
                     const int left = no - q0;
                     const int cnt = left < W ? left : W;  // opponents evaluated in this pass
-                    mtw_ensure<W>(np_, j, (uint32_t)(2 * cnt));
+                    mtw_ensure<W>(np_, j, s.gshift, (uint32_t)(2 * cnt));
                     bool is_hit = false;
                     if (j < cnt) {
                         const int o = cfg_opp(cfg, team, q0 + j);
@@ -782,6 +859,10 @@ __host__ __device__ inline int obs_wave_bytes(int RS, int N, int M, int obs_byte
 #ifndef OBS_ABLATE
 #define OBS_ABLATE 0
 #endif
+// experiment (G <= 16 only, results wrong beyond): no compiler-tracked load anywhere in the render loop
+#ifndef OBS_NODRAIN
+#define OBS_NODRAIN 0
+#endif
 
 template <int ALIGN>
 struct OutVec;
@@ -895,7 +976,9 @@ __device__ __forceinline__ void obs_build_env(const DevCfg& cfg, const DevPtrs& 
     // ---- hot bits of every tile plane
     if (has_cells) {
         for (int w = lane; w < GW; w += WAVE) {
+#if !OBS_NODRAIN
             if (w >= WAVE) cells = ((const uint32_t*)(p.grid + (size_t)e * cfg.GS))[w];  // G > 16 only
+#endif
             int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
             #pragma unroll
             for (int b = 0; b < 4; b++) {
@@ -1017,10 +1100,17 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
     const int e_end = cfg.n_envs;
     // the first env's state: ordinary loads; every later env's state arrives through the prefetch below
     uint32_t recw = 0, cells = 0;
+#if OBS_NODRAIN
+    if (e_first >= e_end) return;
+    recw = obs_prefetch_dword((const uint32_t*)(p.rec + (size_t)e_first * cfg.RS) + rec_lane);
+    cells = obs_prefetch_dword((const uint32_t*)(p.grid + (size_t)e_first * cfg.GS) + grid_lane);
+    OBS_PREFETCH_DRAIN(recw, cells);
+#else
     if (e_first < e_end) {
         recw = ((const uint32_t*)(p.rec + (size_t)e_first * cfg.RS))[rec_lane];
         cells = ((const uint32_t*)(p.grid + (size_t)e_first * cfg.GS))[grid_lane];
     }
+#endif
 
     for (int e = e_first; e < e_end; e += e_stride) {
         obs_build_env(cfg, p, e, recw, cells, srec, mv, mstage, mlut, bits, slots, reverse_mask, lane, obs != nullptr, meta);
@@ -1070,7 +1160,12 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
                 cells = ((const uint32_t*)(p.grid + (size_t)(e + e_stride) * cfg.GS))[grid_lane];
             }
         } else if (e + e_stride < e_end) {
+#if OBS_NODRAIN
+            recw = obs_prefetch_dword((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS) + rec_lane);
+            OBS_PREFETCH_DRAIN(recw, cells);
+#else
             recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
+#endif
         }
         __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // this env's LDS reads are done before the next env reuses the bitmap
         __builtin_amdgcn_wave_barrier();

@@ -5,7 +5,9 @@ alone moves the render by 20 %, so separate processes cannot be compared).  Usag
 import ctypes, importlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import numpy as np
+if not os.environ.get("AB_BUILD_ONLY"):
+    import torch
 pkg = importlib.import_module("marl-ctf-development_amd")
 abi = pkg._abi
 CS = os.path.join(ROOT, "marl-ctf-development_amd", "csrc")
@@ -29,10 +31,21 @@ for i, flags in enumerate(sys.argv[1:]):
         src = os.path.join(ROOT, src)
     else:
         flags_only = flags
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic",
-                           "-I" + os.path.join(ROOT, "marl-ctf-development_amd", "csrc")]
-                          + flags_only.split() + ["-shared", "-o", so, os.path.join(src, "ctf_abi.hip"), os.path.join(src, "ctf_kernels.hip")])
-    vecs.append((full, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_",)), **kw)))
+    pre = os.path.join(ROOT, "tools", "_ab", f"lib{i}.so")
+    if os.environ.get("AB_PREBUILT") and os.path.exists(pre):
+        so = pre  # built in the CPU container by `AB_BUILD_ONLY=1 python tools/ab_inproc.py ...` (hipcc cross-compiles; no GPU minutes)
+    else:
+        if os.environ.get("AB_BUILD_ONLY"):
+            os.makedirs(os.path.dirname(pre), exist_ok=True)
+            so = pre
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic",
+                               "-I" + os.path.join(ROOT, "marl-ctf-development_amd", "csrc")]
+                              + flags_only.split() + ["-shared", "-o", so, os.path.join(src, "ctf_abi.hip"), os.path.join(src, "ctf_kernels.hip")])
+    if os.environ.get("AB_BUILD_ONLY"):
+        continue
+    vecs.append((full, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_", "ctf_set_rng_states", "ctf_get_rng_states")), **kw)))
+if os.environ.get("AB_BUILD_ONLY"):
+    sys.exit(0)
 shared_obs, shared_meta = vecs[0][1].obs, vecs[0][1].meta
 acts = torch.zeros((E, 8), dtype=torch.int8, device="cuda")
 vecs[0][1].random_actions(acts, seed=5, step=0)
