@@ -130,7 +130,7 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
         !make_fastdiv((uint32_t)d->GG, (uint32_t)(N * d->GG) + 16, &d->div_gg_row) ||
         !make_fastdiv((uint32_t)G, (uint32_t)d->GS + 4, &d->div_g) ||
         !make_fastdiv((uint32_t)d->M, (uint32_t)(N * d->M) + 64, &d->div_m) ||
-        !make_fastdiv((uint32_t)N, (uint32_t)(64 * N) + 64, &d->div_n) ||
+        !make_fastdiv((uint32_t)N, (uint32_t)(256 * N) + 64, &d->div_n) ||
         !make_fastdiv((uint32_t)(d->GS / 16), (uint32_t)(64 * d->GS / 16) + 64, &d->div_gq) ||
         !make_fastdiv((uint32_t)(d->RS / 16), (uint32_t)(64 * d->RS / 16) + 64, &d->div_rq) ||
         !make_fastdiv((uint32_t)(CTF_N_METRICS * N), (uint32_t)(64 * CTF_N_METRICS * N) + 64, &d->div_mn) ||

@@ -53,20 +53,32 @@ for t in range(int(os.environ.get("AB_PRESTEP", 0))):  # spread the agents over 
     for flags, v in vecs:
         v.random_actions(acts, seed=5, step=t)
         v.step(acts, auto_reset=True)
+if os.environ.get("AB_BENCHLIKE"):  # bench.py's protocol: a discarded first episode, staggered episode phases, fresh actions every step
+    phase = torch.arange(E, device="cuda") % 500
+    for flags, v in vecs:
+        for s_ in range(500):
+            v.random_actions(acts, seed=0x5747, step=s_)
+            v.step(acts, auto_reset=True)
+            v.reset((phase == s_).to(torch.uint8))
+ACTS = torch.empty((64, E, 8), dtype=torch.int8, device="cuda")
+for t in range(64):
+    vecs[0][1].random_actions(ACTS[t], seed=0xC7F, step=t)
+if not os.environ.get("AB_BENCHLIKE"):
+    ACTS[:] = acts
 res = {f: ([], [], []) for f, _ in vecs}
 os.environ["CTF_FUSED"] = os.environ.get("AB_FUSED", "1")  # step_observe below: the single launch where the build has one
 for rnd in range(4):
     for flags, v in vecs:
         os.environ.update(ENVS[flags])
         v.obs, v.meta = shared_obs, shared_meta
-        for _ in range(10):
-            v.step(acts, auto_reset=True); v.observe()
+        for t in range(10):
+            v.step(ACTS[t], auto_reset=True); v.observe()
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(60)]
-        for a, b, c in ev:
-            a.record(); v.step(acts, auto_reset=True); b.record(); v.observe(); c.record()
+        for t, (a, b, c) in enumerate(ev):
+            a.record(); v.step(ACTS[t % 64], auto_reset=True); b.record(); v.observe(); c.record()
         ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(60)]
-        for a, b in ev2:
-            a.record(); v.step_observe(acts, auto_reset=True); b.record()
+        for t, (a, b) in enumerate(ev2):
+            a.record(); v.step_observe(ACTS[(t + 7) % 64], auto_reset=True); b.record()
         torch.cuda.synchronize()
         for k in ENVS[flags]:
             del os.environ[k]
