@@ -145,7 +145,9 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     vec.observe()  # allocates (and places) the observation buffer
     if stagger:
         stagger_phases(vec, torch, lo, kwargs["GAME_STEPS"])
-    observe_kernel = "k_observe"
+    obs_bytes = N * C * G * G   # ctf_launch_observe's rule: one-shot 8 KiB tiles whenever an env's block allows them
+    tiles = obs_bytes % 16 == 0 and obs_bytes >= 8192 and os.environ.get("CTF_OBS_TILES", "1") != "0"
+    observe_kernel = "k_observe_tiles" if tiles else "k_observe"
 
     def one_step(t, events=None):
         if gather is not None:
@@ -213,6 +215,7 @@ def roofline_of(r, traffic_table):
     kernel, per_env, ms = r["observe_kernel"], observe_algorithmic_bytes(N, C, G), r["k_observe_ms"]
     achieved = per_env * E / (ms * 1e-3) / 1e9
     entry = traffic_table.get(f"{r['name']}_{E}", {})
+    hbm = entry.get("k_observe_hbm_bytes_per_launch") if entry.get("kernel", "k_observe") == kernel else None
     return {
         "bound": "hbm",
         "kernel": kernel,
@@ -220,9 +223,9 @@ def roofline_of(r, traffic_table):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": entry.get(f"{kernel}_hbm_bytes_per_launch"),
+        "traffic": hbm,
         "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of " + entry.get("source", "?") +
-                           ", not measured in this run)") if entry.get(f"{kernel}_hbm_bytes_per_launch") else None,
+                           ", not measured in this run)") if hbm else None,
         "algorithmic_bytes_per_env": per_env,
         "avg_launch_ms": ms,
     }

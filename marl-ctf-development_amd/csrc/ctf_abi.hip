@@ -83,7 +83,55 @@ static bool make_fastdiv(uint32_t d, uint32_t n_max, FastDiv* out) {
     return true;
 }
 
+// the same reciprocal, needed (and checked) only for the multiples of `stride` below n_max
+static bool make_fastdiv_strided(uint32_t d, uint64_t n_max, uint32_t stride, FastDiv* out) {
+    int nbits = 1;
+    while ((1ull << nbits) < n_max + 1) nbits++;
+    const int s = nbits + ceil_log2(d);
+    if (s > 62) return false;
+    const uint64_t m = ((1ull << s) + d - 1) / d;
+    if (m > 0xFFFFFFFFull) return false;
+    out->m = (uint32_t)m;
+    out->s = (uint32_t)s;
+    for (uint64_t n = 0; n < n_max; n += stride)
+        if ((uint32_t)((n * out->m) >> out->s) != (uint32_t)(n / d)) return false;
+    return true;
+}
+static int gcd_int(int a, int b) { return b ? gcd_int(b, a % b) : a; }
+
 static int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// Which of the env's distinct metadata values (mv[] of obs_build_env: 0 step fraction, 1 + t capture ratio for a viewer of
+// team t, 4 + j uint8-truncated hp of agent j, 20 + j has_flag[j], 40 = 1.0, 41 = 0.0) element k of viewer i's row shows
+// (gridworld_ctf.py:1044-1067) — the host twin of obs_meta_lut in ctf_kernels.hip, for the kernels that cannot afford to
+// rebuild the table per wave.
+static void host_meta_lut(const DevCfg& d, uint8_t* out) {
+    const int N = d.N, M = d.M;
+    for (int i = 0; i < N; i++)
+        for (int k = 0; k < M; k++) {
+            const int team = d.team[i];
+            int src = 41;
+            if (k == 0) src = 0;
+            else if (k == 1) src = 1 + team;
+            else if (k < 6) src = (k - 2 == d.type[i]) ? 40 : 41;
+            else {
+                int who = i;
+                if (k >= 8) {
+                    const int pidx = (k - 8) >> 1;
+                    const int n_own = d.n_opp[1 - team], n_op = d.n_opp[team];
+                    int self_idx = 15;
+                    for (int q = n_own - 1; q >= 0; q--)
+                        if (d.opp[1 - team][q] == i) self_idx = q;
+                    const int n_mates = n_own - (self_idx < n_own ? 1 : 0);
+                    if (pidx < n_mates) who = d.opp[1 - team][pidx + (pidx >= self_idx ? 1 : 0)];
+                    else if (pidx - n_mates < n_op) who = d.opp[team][pidx - n_mates];
+                    else who = -1;
+                }
+                if (who >= 0) src = ((k & 1) ? 20 : 4) + who;
+            }
+            out[i * M + k] = (uint8_t)src;
+        }
+}
 
 static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     memset(d, 0, sizeof(*d));
@@ -136,6 +184,13 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
         !make_fastdiv((uint32_t)(CTF_N_METRICS * N), (uint32_t)(64 * CTF_N_METRICS * N) + 64, &d->div_mn) ||
         !make_fastdiv((uint32_t)((CTF_N_METRICS * N + 3) / 4), (uint32_t)(64 * ((CTF_N_METRICS * N + 3) / 4)) + 64, &d->div_mw))
         return fail(CTF_E_INVALID, "internal: reciprocal division not exact for these dimensions");
+    d->tile_k = d->tile_tpg = 0;  // 0: no tile render for this configuration
+    if (d->obs_bytes % 16 == 0 && d->obs_bytes >= CTF_OBS_TILE) {
+        d->tile_k = CTF_OBS_TILE / gcd_int(d->obs_bytes, CTF_OBS_TILE);
+        d->tile_tpg = (int)((int64_t)d->tile_k * d->obs_bytes / CTF_OBS_TILE);
+        if (!make_fastdiv_strided((uint32_t)d->obs_bytes, (uint64_t)d->tile_k * d->obs_bytes + CTF_OBS_TILE, CTF_OBS_TILE, &d->div_ob_tile))
+            d->tile_k = d->tile_tpg = 0;
+    }
     if (const char* ov = getenv("CTF_STEP_W")) {
         const int w = atoi(ov);
         if (w == 1 || w == 2 || w == 4 || w == 8) d->step_lanes_override = w;
@@ -201,7 +256,7 @@ static void free_all(ctf_env* h) {
     if (!h) return;
     (void)hipFree(h->p.grid); (void)hipFree(h->p.rec); (void)hipFree(h->p.mt_py); (void)hipFree(h->p.mt_np);
     (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis); (void)hipFree(h->p.vislog);
-    (void)hipFree((void*)h->p.init_grid); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
+    (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
     delete h;
 }
 
@@ -237,12 +292,16 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     ALLOC(h->p.vis, vis_elems * 4);
     ALLOC(h->p.vislog, (d.log_metrics ? (size_t)CTF_VIS_LOG * E * d.N : 1) * 2);
     ALLOC(h->p.init_grid, (size_t)d.GS);
+    ALLOC(h->p.meta_lut, (size_t)round_up(d.N * d.M, 16));
     ALLOC(h->p.status, 4);
     ALLOC(h->seed_scratch, E * 2 * 8);
 #undef ALLOC
     std::vector<uint8_t> g0((size_t)d.GS, 0);
     memcpy(g0.data(), cfg->init_grid, (size_t)d.GG);
     hipError_t e1 = hipMemcpy((void*)h->p.init_grid, g0.data(), (size_t)d.GS, hipMemcpyHostToDevice);
+    std::vector<uint8_t> lut((size_t)round_up(d.N * d.M, 16), 41);
+    host_meta_lut(d, lut.data());
+    if (hipMemcpy((void*)h->p.meta_lut, lut.data(), lut.size(), hipMemcpyHostToDevice) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "device initialisation failed"); }
     hipError_t e2 = hipMemset(h->p.status, 0, 4);
     hipError_t e3 = hipMemset(h->p.rec, 0, E * d.RS);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "device initialisation failed"); }

@@ -22,6 +22,7 @@
 #include "../../include/ctf_env.h"
 
 #define CTF_TILE_NONE 15u  // channel code of a tile that has no observation plane
+#define CTF_OBS_TILE 8192  // bytes of the flat observation buffer one wave of k_observe_tiles renders
 
 struct FastDiv {  // q = (n * m) >> s, exact for every n the kernels use (verified on the host at create)
     uint32_t m, s;
@@ -39,6 +40,10 @@ struct DevCfg {
     FastDiv div_cgg, div_gg, div_g, div_m, div_n, div_gq, div_rq, div_mn, div_mw;
     FastDiv div_gg_row;             // / GG over 0 .. N*GG (the compact observation's rows)
     int32_t step_lanes_override;    // 0 = automatic; set from CTF_STEP_W for profiling
+    // the tile render (k_observe_tiles): envs are taken in groups of tile_k, the smallest count whose blocks fill a whole
+    // number (tile_tpg) of tiles; div_ob_tile divides a tile's byte offset inside its group (a multiple of the tile size) by obs_bytes
+    int32_t tile_k, tile_tpg;
+    FastDiv div_ob_tile;
     double heal, tag_p, guard_mult, vault_cost, vault_min;
     double r_capture, r_step, r_tag, win_scalar, loss_scalar, punish;
     double type_hp[4], type_damage[4];
@@ -65,6 +70,7 @@ struct DevPtrs {
     uint32_t* vis;             // base maps u32 [E][N][GS]; valid only when the env's CTF_F_BASE_ZERO flag is clear
     uint16_t* vislog;          // u16 [CTF_VIS_LOG][E][N]
     const uint8_t* init_grid;  // GS bytes
+    const uint8_t* meta_lut;   // N * M bytes: which of the env's few distinct metadata values each element of the N x M block shows
     uint32_t* status;
 };
 

@@ -853,6 +853,9 @@ __host__ __device__ inline int obs_wave_bytes(int RS, int N, int M, int obs_byte
     return RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M) + obs_meta_lut_bytes(N, M) + obs_bitmap_bytes(obs_bytes);
 }
 
+#ifndef OBS_TILES_DEFAULT
+#define OBS_TILES_DEFAULT 1  // ctf_launch_observe takes the tile render whenever it applies (CTF_OBS_TILES=0 / 1 overrides)
+#endif
 #define LGKM_ONLY 0xC07F  // s_waitcnt lgkmcnt(0): LDS traffic only — never drain the wave's outstanding stores
 // Profiling-only ablations (never defined in the shipped build; see tools/ablate.sh):
 //   bit0 no bit expansion, bit1 no chunk stores, bit2 no bitmap build, bit3 no metadata, bit4 metadata computed but not stored
@@ -1173,6 +1176,156 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// observe as one-shot TILES — the same bitmap idea, organised by output address instead of by env
+// ------------------------------------------------------------------------------------------------
+// Wave t of the grid renders CTF_OBS_TILE (8 192) consecutive bytes of the FLAT observation buffer and exits: it loads the
+// grid of the (at most two) envs its tile touches, builds only the bits of its own tile — for each of the agent views whose
+// blocks intersect the tile, every non-empty cell gives one candidate bit — and issues eight store instructions.  Why:
+// the chip then writes a compact window that moves linearly through the buffer and a wave issues few stores.  On MI355X a
+// wave that issues 1 / 4 / 8 / 25 store instructions in a row sustains 6.9 / 5.9 / 5.7 / 5.5 TB/s chip-wide, and the long
+// per-wave streams of k_observe lose another 15 % on the "slow" kind of allocation (on some boxes: every allocation) while
+// one-shot tiles do not (tools/store_bw8.hip, profiles/r02_store_bw8_tiles.txt).  The price: the cell scan is repeated by
+// every tile of an env (3.1 tiles per arena env) for the views the tile holds, and every wave pays the prologue — so both are
+// kept lean: envs come in groups whose blocks fill a whole number of tiles (no 64-bit division), a cell's flipped index and
+// its channel code for either viewing team are worked out once per grid dword, a view costs ~7 instructions per cell, and
+// the metadata LUT comes from a table the host built.
+// Metadata rows: written by the wave whose tile holds an env's first byte.
+// Used when an env's block is a multiple of 16 bytes and >= one tile and the buffer is 16-byte aligned (ctf_launch_observe).
+#define OBS_TILE CTF_OBS_TILE
+__host__ __device__ inline int tiles_wave_bytes(int RS, int N, int M) {
+    return OBS_TILE / 8 + RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
+}
+
+__global__ void __launch_bounds__(256) k_observe_tiles(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs, uint16_t* __restrict__ meta,
+                                                       uint32_t reverse_mask) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int N = cfg.N, M = cfg.M, G = cfg.G, GG = cfg.GG, CGG = cfg.CGG, OB = cfg.obs_bytes;
+    // ---- which tile of which group of envs (uniform, 32-bit)
+    const int tt = blockIdx.x * (blockDim.x / WAVE) + wave;
+    if (tt >= cfg.tile_tpg) return;
+    const int env_base = blockIdx.y * cfg.tile_k;
+    const uint32_t lo_local = (uint32_t)tt * OBS_TILE;                  // < tile_k * obs_bytes
+    const int el = (int)fdiv(lo_local, cfg.div_ob_tile);
+    const int off0 = (int)(lo_local - (uint32_t)el * (uint32_t)OB);    // the tile starts at byte off0 of env e0's block
+    const int e0 = env_base + el;
+    if (e0 >= cfg.n_envs) return;
+    const bool two = off0 + OBS_TILE > OB && e0 + 1 < cfg.n_envs;       // the tile runs into env e0 + 1 (obs_bytes >= tile: never further)
+    uint8_t* wl = (uint8_t*)lds + wave * tiles_wave_bytes(cfg.RS, N, M);
+    uint32_t* bits = (uint32_t*)wl;
+    const int GW = cfg.GS / 4;
+    // ---- the views (flat agent blocks) the tile intersects; the last ones may lie in env e0 + 1
+    const int ia0 = (int)fdiv((uint32_t)off0, cfg.div_cgg);
+    const int last = off0 + OBS_TILE - 1;  // relative to env e0's block
+    const int ia1 = last < OB ? (int)fdiv((uint32_t)last, cfg.div_cgg) : N + (int)fdiv((uint32_t)(last - OB), cfg.div_cgg);
+    // ---- loads, all issued before anything waits: the grids' dwords and (lane k: view k) the viewer's two position bytes
+    const uint32_t* g0 = (const uint32_t*)(p.grid + (size_t)e0 * cfg.GS);
+    const uint32_t* g1 = (const uint32_t*)(p.grid + (size_t)(two ? e0 + 1 : e0) * cfg.GS);
+    uint32_t c0[4], c1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // G <= 32: at most 256 grid dwords (uniform conditions)
+        c0[j] = (GW > WAVE * j) ? g0[min(lane + WAVE * j, GW - 1)] : 0u;
+        c1[j] = (GW > WAVE * j && two) ? g1[min(lane + WAVE * j, GW - 1)] : 0u;
+    }
+    uint32_t own_bit = 0xFFFFFFFFu;
+    {
+        const int fa = ia0 + lane;
+        const bool nxt = fa >= N;
+        if (fa <= ia1 && !(nxt && !two)) {
+            const int ik = nxt ? fa - N : fa;
+            const uint16_t rc = *(const uint16_t*)(p.rec + (size_t)(nxt ? e0 + 1 : e0) * cfg.RS + cfg.off_pos + 2 * ik);
+            const int r = (int)(int8_t)(rc & 0xFFu), c = (int)(int8_t)(rc >> 8);
+            const int cell = ((reverse_mask >> ik) & 1u) ? flip_cell(cfg, r * G + c, r, c) : r * G + c;
+            own_bit = (uint32_t)((nxt ? OB : 0) + ik * CGG - off0 + cell);
+        }
+    }
+    for (int q = lane; q < OBS_TILE / 8 / 16; q += WAVE) ((u32x4_t*)bits)[q] = u32x4_t{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);
+    __builtin_amdgcn_wave_barrier();
+    if (own_bit < (uint32_t)OBS_TILE) atomicOr(bits + (own_bit >> 5), 1u << (own_bit & 31u));
+    if (!(OBS_ABLATE & 4)) {
+        const uint32_t lut0_lo = (uint32_t)cfg.chan_lut[0], lut0_hi = (uint32_t)(cfg.chan_lut[0] >> 32);
+        const uint32_t lut1_lo = (uint32_t)cfg.chan_lut[1], lut1_hi = (uint32_t)(cfg.chan_lut[1] >> 32);
+#pragma unroll 1
+        for (int j = 0; j * WAVE < GW; j++) {  // uniform; one pass for G <= 16
+            const int w = lane + WAVE * j;
+            const uint32_t cw0 = j == 0 ? c0[0] : (j == 1 ? c0[1] : (j == 2 ? c0[2] : c0[3]));
+            const uint32_t cw1 = j == 0 ? c1[0] : (j == 1 ? c1[1] : (j == 2 ? c1[2] : c1[3]));
+            // once per grid dword: for its 4 cells the plain and the flipped index and, per env, the channel code for either
+            // viewing team (code NONE also for an empty cell)
+            uint32_t plain[4], flipped[4], code0 = 0, code1 = 0;  // code0 / code1: byte b = (team-1 code << 4 | team-0 code) of env e0 / e0 + 1
+            {
+                int r = (int)fdiv((uint32_t)(w * 4), cfg.div_g), c = w * 4 - r * G;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int cell = w * 4 + b;
+                    const bool in = w < GW && cell < GG;
+                    plain[b] = (uint32_t)cell;
+                    flipped[b] = (uint32_t)flip_cell(cfg, cell, r, c);
+                    const uint32_t v0 = in ? (cw0 >> (8 * b)) & 0xFFu : 0u, v1 = in ? (cw1 >> (8 * b)) & 0xFFu : 0u;
+                    const uint32_t sh0 = 4 * (v0 & 7u), sh1 = 4 * (v1 & 7u);
+                    const uint32_t k00 = v0 ? (((v0 & 8u) ? lut0_hi : lut0_lo) >> sh0) & 15u : CTF_TILE_NONE;
+                    const uint32_t k01 = v0 ? (((v0 & 8u) ? lut1_hi : lut1_lo) >> sh0) & 15u : CTF_TILE_NONE;
+                    const uint32_t k10 = v1 ? (((v1 & 8u) ? lut0_hi : lut0_lo) >> sh1) & 15u : CTF_TILE_NONE;
+                    const uint32_t k11 = v1 ? (((v1 & 8u) ? lut1_hi : lut1_lo) >> sh1) & 15u : CTF_TILE_NONE;
+                    code0 |= (k00 | (k01 << 4)) << (8 * b);
+                    code1 |= (k10 | (k11 << 4)) << (8 * b);
+                    if (++c == G) { c = 0; r++; }
+                }
+            }
+#pragma unroll 1
+            for (int fa = ia0; fa <= ia1; fa++) {  // uniform: the views
+                const bool nxt = fa >= N;
+                if (nxt && !two) break;
+                const int ik = nxt ? fa - N : fa;
+                const int tsh = (int)((cfg.team_mask >> ik) & 1u) * 4;
+                const bool rev = (reverse_mask >> ik) & 1u;
+                const int base = (nxt ? OB : 0) + ik * CGG - off0;  // the view's block starts at tile bit `base` (may be negative)
+                const uint32_t codes = nxt ? code1 : code0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t code = (codes >> (8 * b + tsh)) & 15u;
+                    const uint32_t bit = (uint32_t)(base + (int)(code * (uint32_t)GG + (rev ? flipped[b] : plain[b])));
+                    if (code != CTF_TILE_NONE && bit < (uint32_t)OBS_TILE) atomicOr(bits + (bit >> 5), 1u << (bit & 31u));
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // the atomic ORs have landed
+    __builtin_amdgcn_wave_barrier();
+    // ---- stream: TILE / 1 KiB store instructions, their bitmap halfwords read first (obs_bytes % 16 == 0: whole chunks)
+    {
+        const uint16_t* hb = (const uint16_t*)bits;
+        const unsigned long long lo = (unsigned long long)env_base * (unsigned long long)OB + lo_local;
+        const unsigned long long left = (unsigned long long)cfg.n_envs * (unsigned long long)OB - lo;
+        const int nchunk = (int)((left < (unsigned long long)OBS_TILE ? left : (unsigned long long)OBS_TILE) >> 4);
+        uint8_t* out = obs + lo;
+        uint32_t h[OBS_TILE / 1024];
+#pragma unroll
+        for (int u = 0; u < OBS_TILE / 1024; u++) h[u] = hb[u * WAVE + lane];
+#pragma unroll
+        for (int u = 0; u < OBS_TILE / 1024; u++) {
+            const int k = u * WAVE + lane;
+            const u32x4_t v = {expand4(h[u], 0), expand4(h[u], 1), expand4(h[u], 2), expand4(h[u], 3)};
+            if (k < nchunk && !(OBS_ABLATE & 2)) *(u32x4_t*)(out + ((size_t)k << 4)) = v;
+        }
+    }
+    // ---- metadata rows of the env whose block starts in this tile (behind the stores: off the stream's path)
+    const bool starts0 = off0 == 0;
+    if (meta && (starts0 || two) && !(OBS_ABLATE & 8)) {
+        const int em = starts0 ? e0 : e0 + 1;
+        uint8_t* srec = wl + OBS_TILE / 8;
+        uint16_t* mv = (uint16_t*)(srec + cfg.RS);
+        uint16_t* mstage = (uint16_t*)(srec + cfg.RS + OBS_MV_BYTES);
+        const uint32_t recw = ((const uint32_t*)(p.rec + (size_t)em * cfg.RS))[min(lane, cfg.RS / 4 - 1)];
+        if (lane == 0) { mv[40] = 0x3C00u; mv[41] = 0u; }
+        const ObsSlots none = {{0u, 0u, 0u, 0u}};
+        obs_build_env(cfg, p, em, recw, 0u, srec, mv, mstage, p.meta_lut, nullptr, none, reverse_mask, lane, false, meta);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // compact observation: one byte per (agent, cell)
 // ------------------------------------------------------------------------------------------------
 // standardise_state's planes 1..C-1 are one-hot per cell (plane k+1 = (relabelled grid == TILES_USED[k]),
@@ -1439,6 +1592,16 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
                                          int n_cus, hipStream_t st) {
     const uintptr_t a = (uintptr_t)obs;
     const int align = ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0) ? 16 : (((cfg.obs_bytes % 4) == 0 && (a % 4) == 0) ? 4 : 1);
+    const char* tenv = getenv("CTF_OBS_TILES");  // 0 / 1: never / whenever possible (tests, profiling)
+    const bool tiles = obs && align == 16 && cfg.tile_k > 0 && (tenv ? atoi(tenv) != 0 : OBS_TILES_DEFAULT);
+    if (tiles) {
+        // one wave per tile, 4 independent waves per block; grid.y = groups of tile_k envs (their blocks fill tile_tpg tiles)
+        const int wpb = 4;
+        const size_t sh = (size_t)wpb * tiles_wave_bytes(cfg.RS, cfg.N, cfg.M);
+        const dim3 grid((unsigned)((cfg.tile_tpg + wpb - 1) / wpb), (unsigned)((cfg.n_envs + cfg.tile_k - 1) / cfg.tile_k));
+        hipLaunchKernelGGL(k_observe_tiles, grid, dim3(wpb * WAVE), sh, st, cfg, p, obs, meta, reverse_mask);
+        return hipGetLastError();
+    }
     // waves per block: 4 unless one env's bitmap is so large that 4 of them would crowd the CU's LDS
     const int per_wave = obs_wave_bytes(cfg.RS, cfg.N, cfg.M, cfg.obs_bytes);
     int wpb = 4;

@@ -107,7 +107,11 @@ def test_golden_trajectory(name):
     ("syn_edge_k1", 64, 150, True),
     ("donut_1v1", 77, 110, True),         # obs block only 2-byte aligned (byte-store path)
 ])
-def test_batch_matches_oracle(name, n_envs, steps, log_metrics):
+@pytest.mark.parametrize("tiles", [0, 1])
+def test_batch_matches_oracle(name, n_envs, steps, log_metrics, tiles, monkeypatch):
+    """``tiles``: the render as the wave-per-env kernel (k_observe) or as one-shot 4 KiB tiles (k_observe_tiles; taken
+    whenever an env's block is 16-byte aligned and >= 4 KiB, the wave-per-env kernel otherwise)."""
+    monkeypatch.setenv("CTF_OBS_TILES", str(tiles))
     case = Case(name)
     auto_reset = name == "arena_stress"
     seeds = np.arange(n_envs, dtype=np.uint64) * 977 + 5
@@ -205,14 +209,15 @@ def _workload(name):
     return dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
 
 
-@pytest.mark.parametrize("workload,auto_reset", [("arena", True), ("arena", False), ("arena20", True)])
-def test_bench_variant_at_bench_size_over_an_episode_end_and_a_visitation_fold(workload, auto_reset):
+@pytest.mark.parametrize("workload,auto_reset,tiles", [("arena", True, 0), ("arena", False, 1), ("arena20", True, 1), ("arena", True, 1)])
+def test_bench_variant_at_bench_size_over_an_episode_end_and_a_visitation_fold(workload, auto_reset, tiles, monkeypatch):
     """The kernel variant bench.py times — metrics counters + visitation log ON, 65 536 envs — for 520 steps: with
     auto_reset the episode ends at step 500 and every env is reset inside the step launch; without it the envs run past
     GAME_STEPS and cross the 511-step in-kernel fold of the visitation log (gridworld_ctf.py:849-918, :479-486).  A 64-env
     sample is stepped through the oracle beside the GPU and compared after EVERY step (rewards f64, done, all N
     observations, all N metadata rows); at the end: every counter of ``counters()`` for the sample, the full state views
     (visitation maps included) and both MT19937 states.  Size-independent properties hold on all 65 536 envs throughout."""
+    monkeypatch.setenv("CTF_OBS_TILES", str(tiles))
     kw = _workload(workload)
     E, steps = 65536, 520
     seeds = np.arange(E, dtype=np.uint64) + 2_000_006
@@ -272,11 +277,12 @@ def test_bench_variant_at_bench_size_over_an_episode_end_and_a_visitation_fold(w
     vec.close()
 
 
-@pytest.mark.parametrize("workload", ["arena", "arena20", "split"])
-def test_full_size_renders_are_run_to_run_identical(workload):
+@pytest.mark.parametrize("workload,tiles", [("arena", 0), ("arena", 1), ("arena20", 1), ("split", 0)])
+def test_full_size_renders_are_run_to_run_identical(workload, tiles, monkeypatch):
     """The render's next-env state arrives through hand-placed loads with counted waits (ctf_kernels.hip): a wait that is
     one store short would show up as rare, timing-dependent differences at full size only.  Both renders, four runs each
     into fresh buffers on a busy device, must be identical — and equal to each other through expand_codes."""
+    monkeypatch.setenv("CTF_OBS_TILES", str(tiles))
     kw = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow) if workload == "split" else _workload(workload)
     E = 65536
     vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=np.arange(E) + 3, np_seeds=np.arange(E) + 3, **kw)

@@ -65,13 +65,17 @@ def main():
         if path:
             pmc_pass(path, p, out)
     json.dump(out, open(os.path.join(root, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-    obs = next((v for k, v in out.items() if "k_observe" in k and "WRITE_SIZE" in v and "FETCH_SIZE" in v), None)
+    # the render of this run: the tile kernel when it ran, else the wave-per-env kernel (never k_observe_codes)
+    cands = [(k, v) for k, v in out.items() if "k_observe" in k and "codes" not in k and "WRITE_SIZE" in v and "FETCH_SIZE" in v]
+    cands.sort(key=lambda kv: -kv[1]["WRITE_SIZE"] * kv[1].get("launches@pmc_write", 1))
+    obs = cands[0][1] if cands else None
+    obs_name = ("k_observe_tiles" if "tiles" in cands[0][0] else "k_observe") if cands else None
     if obs:
         tpath = os.path.join(root, "traffic.json")
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
         w, r = obs["WRITE_SIZE"] * 1024.0, obs["FETCH_SIZE"] * 1024.0 * 2.0
         traffic[key] = {
-            "k_observe_hbm_bytes_per_launch": w + r, "write_bytes": w, "fetch_bytes_corrected_x2": r, "source": tag,
+            "kernel": obs_name, "k_observe_hbm_bytes_per_launch": w + r, "write_bytes": w, "fetch_bytes_corrected_x2": r, "source": tag,
             "note": "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate passes (tools/profile.sh), KiB units x1024; "
                     "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read; our "
                     "reads are 4 B/lane so the read side, 1% of the total, is approximate)"}
