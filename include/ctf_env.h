@@ -174,7 +174,9 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  *   obs_dev      uint8 [E][N][C][G][G] or NULL
  *   meta_dev     IEEE binary16 bits [E][N][M], M = 2N+6, or NULL
  *   reverse_mask bit i = reverse_grid for agent i; CTF_REVERSE_DEFAULT = (team(i) == 1), the value
- *                every caller in the reference passes (ppo.py:69,87; utils.py:535) */
+ *                every caller in the reference passes (ppo.py:69,87; utils.py:535)
+ * One launch: k_observe_tiles (one wave per 8 KiB of the flat buffer) when an env's block is a multiple of 16 bytes and at
+ * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way. */
 #define CTF_REVERSE_DEFAULT 0xFFFFFFFFu
 int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t reverse_mask, void* stream);
 
