@@ -188,8 +188,12 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     if (d->obs_bytes % 16 == 0 && d->obs_bytes >= CTF_OBS_TILE) {
         d->tile_k = CTF_OBS_TILE / gcd_int(d->obs_bytes, CTF_OBS_TILE);
         d->tile_tpg = (int)((int64_t)d->tile_k * d->obs_bytes / CTF_OBS_TILE);
-        if (!make_fastdiv_strided((uint32_t)d->obs_bytes, (uint64_t)d->tile_k * d->obs_bytes + CTF_OBS_TILE, CTF_OBS_TILE, &d->div_ob_tile))
-            d->tile_k = d->tile_tpg = 0;
+        d->tile_bx = (d->tile_tpg + CTF_OBS_TILE_WPB - 1) / CTF_OBS_TILE_WPB;
+        const int64_t nb = ((int64_t)d->tile_bx * ((n_envs + d->tile_k - 1) / d->tile_k) + 7) / 8 * 8;
+        d->tile_nb = (int32_t)nb;
+        if (nb > 0x3FFFFFFF || !make_fastdiv((uint32_t)d->tile_bx, (uint32_t)nb + 8, &d->div_tile_bx) ||
+            !make_fastdiv_strided((uint32_t)d->obs_bytes, (uint64_t)d->tile_k * d->obs_bytes + CTF_OBS_TILE, CTF_OBS_TILE, &d->div_ob_tile))
+            d->tile_k = d->tile_tpg = d->tile_bx = d->tile_nb = 0;
     }
     if (const char* ov = getenv("CTF_STEP_W")) {
         const int w = atoi(ov);

@@ -22,7 +22,8 @@
 #include "../../include/ctf_env.h"
 
 #define CTF_TILE_NONE 15u  // channel code of a tile that has no observation plane
-#define CTF_OBS_TILE 8192  // bytes of the flat observation buffer one wave of k_observe_tiles renders
+#define CTF_OBS_TILE 8192
+#define CTF_OBS_TILE_WPB 4  // independent one-wave tiles per block  // bytes of the flat observation buffer one wave of k_observe_tiles renders
 
 struct FastDiv {  // q = (n * m) >> s, exact for every n the kernels use (verified on the host at create)
     uint32_t m, s;
@@ -44,6 +45,10 @@ struct DevCfg {
     // number (tile_tpg) of tiles; div_ob_tile divides a tile's byte offset inside its group (a multiple of the tile size) by obs_bytes
     int32_t tile_k, tile_tpg;
     FastDiv div_ob_tile;
+    // its launch is 1-D: tile_nb blocks (a multiple of 8) of CTF_OBS_TILE_WPB tiles, tile_bx blocks per env group; div_tile_bx
+    // splits a block index into (group, block in group)
+    int32_t tile_bx, tile_nb;
+    FastDiv div_tile_bx;
     double heal, tag_p, guard_mult, vault_cost, vault_min;
     double r_capture, r_step, r_tag, win_scalar, loss_scalar, punish;
     double type_hp[4], type_damage[4];
