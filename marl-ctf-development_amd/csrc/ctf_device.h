@@ -22,8 +22,10 @@
 #include "../../include/ctf_env.h"
 
 #define CTF_TILE_NONE 15u  // channel code of a tile that has no observation plane
-#define CTF_OBS_TILE 8192
-#define CTF_OBS_TILE_WPB 4  // independent one-wave tiles per block  // bytes of the flat observation buffer one wave of k_observe_tiles renders
+#ifndef CTF_OBS_TILE
+#define CTF_OBS_TILE 8192  // bytes of the flat observation buffer one wave of k_observe_tiles renders (-D: profiling)
+#endif
+#define CTF_OBS_TILE_WPB 4  // independent one-wave tiles per block
 
 struct FastDiv {  // q = (n * m) >> s, exact for every n the kernels use (verified on the host at create)
     uint32_t m, s;
