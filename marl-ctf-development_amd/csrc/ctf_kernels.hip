@@ -1083,7 +1083,7 @@ __device__ __forceinline__ void obs_store_chunk(uint8_t* out, uint32_t h, int k,
 // dependent chain is too long, and 24 streaming waves per CU drive the store path less well than 32.)
 template <int ALIGN>
 __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs,
-                                                 uint16_t* __restrict__ meta, uint32_t reverse_mask) {
+                                                 uint16_t* __restrict__ meta, uint32_t reverse_mask, uint32_t xcd_map) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
@@ -1099,8 +1099,15 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
     if (meta) obs_meta_lut(cfg, mlut, mv, lane);
     const int GW = cfg.GS / 4;
     const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
-    const int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb;
-    const int e_end = cfg.n_envs;
+    // Consecutive workgroups go to consecutive XCDs: with xcd_map (grid a multiple of 8 blocks) XCD x renders ITS OWN contiguous
+    // eighth of the envs instead of every XCD writing into every page of the buffer (see k_observe_tiles).
+    int e_first = blockIdx.x * wpb + wave, e_stride = gridDim.x * wpb, e_end = cfg.n_envs;
+    if (xcd_map) {
+        const int chunk = (cfg.n_envs + 7) >> 3, lo = (int)(blockIdx.x & 7u) * chunk;
+        e_first = lo + (int)(blockIdx.x >> 3) * wpb + wave;
+        e_stride = (int)(gridDim.x >> 3) * wpb;
+        e_end = min(lo + chunk, cfg.n_envs);
+    }
     // the first env's state: ordinary loads; every later env's state arrives through the prefetch below
     uint32_t recw = 0, cells = 0;
 #if OBS_NODRAIN
@@ -1626,9 +1633,11 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     if (cap > 64) cap -= obs_reserve_blocks();
     if (blocks > cap) blocks = cap;
     const dim3 grid(blocks), block(wpb * WAVE);
-    if (align == 16) hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
-    else if (align == 4) hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
-    else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask);
+    const char* xenv = getenv("CTF_OBS_XCD");  // 0: plain grid-stride split of the envs (profiling)
+    const uint32_t xcd_map = (blocks % 8 == 0 && (xenv ? atoi(xenv) != 0 : true)) ? 1u : 0u;
+    if (align == 16) hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
+    else if (align == 4) hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
+    else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint16_t* meta, uint16_t* selfcells,
