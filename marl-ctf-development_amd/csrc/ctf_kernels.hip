@@ -206,6 +206,27 @@ __device__ __forceinline__ double sel4(const double* t, int k) {
 #ifndef STEP_ABLATE
 #define STEP_ABLATE 0
 #endif
+// Profiling-only phase trace of the step kernel (tools/trace_step.py): lane 0 of every block stamps the 100 MHz
+// wall clock at fixed points of the step (1: every phase, 2: start / end only); never defined in the shipped build.
+#ifndef STEP_TRACE
+#define STEP_TRACE 0
+#endif
+#if STEP_TRACE
+__device__ unsigned long long g_step_trace[8192][40];
+__device__ unsigned long long g_step_span[8192][3];  // every block: start, end, HW_ID
+#define STEP_STAMP(k) do { if (threadIdx.x == 0 && (STEP_TRACE == 1 || (k) == 0 || (k) == 32)) { const unsigned long long t_ = wall_clock64(); \
+        if (STEP_TRACE == 1 && blockIdx.x < 8192) g_step_trace[blockIdx.x][(k)] = t_; \
+        if ((k) == 0 && blockIdx.x < 8192) { g_step_span[blockIdx.x][0] = t_; g_step_span[blockIdx.x][2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); } \
+        if ((k) == 32 && blockIdx.x < 8192) g_step_span[blockIdx.x][1] = t_; } } while (0)
+extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_trace), sizeof(g_step_trace));
+}
+extern "C" int ctf_debug_step_span(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_span), sizeof(g_step_span));
+}
+#else
+#define STEP_STAMP(k) do { } while (0)
+#endif
 
 __host__ __device__ inline int step_slot_bytes(int GS, int RS, int N, bool metrics) {
     int b = GS + RS + 16 + 2 * WCAP * 4 + (metrics ? ((CTF_N_METRICS * N + 3) & ~3) : 0);
@@ -405,6 +426,12 @@ template <bool METRICS, int W>
 __device__ __forceinline__ void metric_add(const DevCfg& cfg, const StepCtx<W>& s, int m, int a, int v) {
     if (METRICS && s.lead) s.sm[m * cfg.N + a] += (uint8_t)v;  // per-step deltas stay far below 256
 }
+// a counter that agent a's turn touches exactly once per step: a plain store instead of an LDS read-modify-write (the deltas
+// start the step at zero), so that consecutive updates do not wait for each other's reads
+template <bool METRICS, int W>
+__device__ __forceinline__ void metric_set(const DevCfg& cfg, const StepCtx<W>& s, int m, int a, int v) {
+    if (METRICS && s.lead) s.sm[m * cfg.N + a] = (uint8_t)v;
+}
 
 // respawn, gridworld_ctf.py:761-794 (all lanes of the group compute; sub-lane 0 writes)
 template <int W>
@@ -488,12 +515,14 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
         // top the CPython window up while the whole wave is at the same point (rejection sampling lets the groups'
         // stream positions diverge; refilling on demand would re-run the refill per group)
         if (!(STEP_ABLATE & 4)) mtw_cycle<W>(py, j, s.gshift);
+        STEP_STAMP(phase == 0 ? 2 : 28);
 #pragma unroll 1
         for (int i = (STEP_ABLATE & 4) ? 0 : N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
             const uint32_t r = py_randbelow<W>(py, j, s.gshift, (uint32_t)i + 1u);
             const uint64_t vi = (perm >> (4 * i)) & 15u, vr = (perm >> (4 * r)) & 15u;
             perm = (perm & ~((uint64_t)15u << (4 * i)) & ~((uint64_t)15u << (4 * r))) | (vr << (4 * i)) | (vi << (4 * r));
         }
+        STEP_STAMP(phase == 0 ? 3 : 29);
         if (phase == 1) break;
 
 #pragma unroll 1
@@ -571,6 +600,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
                 }
             }
 
+            STEP_STAMP(4 + 3 * (k & 7));
             // ---- tagging_logic (:796-837): sub-lane q evaluates opponent q0+q; hits are applied in opponent order
             const double dmg = sel4(cfg.type_damage, type);
             if (!(STEP_ABLATE & 1) && dmg > 0) {
@@ -613,12 +643,13 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
                 }
             }
 
+            STEP_STAMP(5 + 3 * (k & 7));
             // ---- metric-only section (:879-902): one teammate / opponent per sub-lane
             if (METRICS && !(STEP_ABLATE & 2)) {
                 if (cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)) <= 3)
-                    metric_add<METRICS>(cfg, s, CTF_M_STEPS_DEFENDING_ZONE, a, 1);
+                    metric_set<METRICS>(cfg, s, CTF_M_STEPS_DEFENDING_ZONE, a, 1);
                 if (cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)) <= 3)
-                    metric_add<METRICS>(cfg, s, CTF_M_STEPS_ATTACKING_ZONE, a, 1);
+                    metric_set<METRICS>(cfg, s, CTF_M_STEPS_ATTACKING_ZONE, a, 1);
                 const int n_own = cfg_nopp(cfg, 1 - team), n_opp = cfg_nopp(cfg, team);
                 int adj_own = 0, adj_opp = 0;
                 for (int q = j; q < 8; q += W) {  // lists hold at most 8 agents
@@ -635,9 +666,10 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
                     adj_opp += __popc(s.ballot(near_opp));
                     if (q - j + W >= (n_own > n_opp ? n_own : n_opp)) break;  // group-uniform exit
                 }
-                metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_TEAMMATE, a, adj_own);
-                metric_add<METRICS>(cfg, s, CTF_M_STEPS_ADJ_OPPONENT, a, adj_opp);
+                metric_set<METRICS>(cfg, s, CTF_M_STEPS_ADJ_TEAMMATE, a, adj_own);
+                metric_set<METRICS>(cfg, s, CTF_M_STEPS_ADJ_OPPONENT, a, adj_opp);
             }
+            STEP_STAMP(6 + 3 * (k & 7));
         }
     }  // phase
 
@@ -677,6 +709,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
         }
     }
 
+    STEP_STAMP(30);
     // ---- the replicated registers go back to the record (sub-lane 0)
     if (s.lead) {
         misc[0] = step;
@@ -695,12 +728,17 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
 }
 
 template <bool METRICS, int W>
-__global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
+__global__ void __launch_bounds__(WAVE)
+#if STEP_TRACE
+__attribute__((amdgpu_waves_per_eu(4, 4)))  // a trace must keep the shipped kernel's residency (16 blocks per CU)
+#endif
+k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
                                                 float* __restrict__ rw32, double* __restrict__ rw64,
                                                 uint8_t* __restrict__ done_out, uint32_t flags) {
     constexpr int EPW = WAVE / W;  // envs per wave
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
+    STEP_STAMP(0);
     const int g = lane / W, j = lane % W;
     const int env0 = blockIdx.x * EPW;
     const int nvalid = min(EPW, cfg.n_envs - env0);
@@ -709,6 +747,12 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
     const int AW = 4, WW = 2 * WCAP;  // action words, RNG window words per slot
     const int N = cfg.N;
     const int e = env0 + g;
+    // the two stream positions: asked for before the staging loads, needed right behind the barrier
+    uint32_t rp_py = 0, rp_np = 0;
+    if (g < nvalid) {
+        rp_py = p.rngpos[2 * e];
+        rp_np = p.rngpos[2 * e + 1];
+    }
 
     // ---- stage the wave's envs' grids, records and actions into LDS.  Flat, coalesced 16-byte loads, unrolled so
     // that every lane has several independent loads in flight (a rolled per-env loop pays one memory latency per env).
@@ -747,6 +791,7 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
         }
     }
     __syncthreads();
+    STEP_STAMP(1);
 
     if (g < nvalid) {
         StepCtx<W> s;
@@ -760,8 +805,8 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
         const int8_t* act = (const int8_t*)(s.sr + cfg.RS);
         int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
 
-        MtWin py = mtw_open(p.mt_py + (size_t)e * CTF_MT_N, wins, p.rngpos[2 * e]);
-        MtWin npg = mtw_open(p.mt_np + (size_t)e * CTF_MT_N, wins + WCAP, p.rngpos[2 * e + 1]);
+        MtWin py = mtw_open(p.mt_py + (size_t)e * CTF_MT_N, wins, rp_py);
+        MtWin npg = mtw_open(p.mt_np + (size_t)e * CTF_MT_N, wins + WCAP, rp_np);
 
         if ((flags & CTF_STEP_AUTO_RESET) && (misc[3] & CTF_F_DONE)) {
             // reset() of this env inside the step launch (not in the reference: opt-in flag); the group's lanes share the copies
@@ -784,6 +829,7 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
             p.rngpos[2 * e + 1] = npg.pos | (npg.lazy ? CTF_LAZY_BIT : 0u);
             if (status) atomicOr(p.status, status);
         }
+        STEP_STAMP(31);
     }
     __syncthreads();
 
@@ -829,6 +875,7 @@ __global__ void __launch_bounds__(WAVE) k_step(DevCfg cfg, DevPtrs p, const int8
             }
         }
     }
+    STEP_STAMP(32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1598,6 +1645,18 @@ extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const
     else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, st);
     return hipGetLastError();
 }
+#if STEP_TRACE
+// what the runtime thinks fits: blocks of k_step<true, 4> per CU at `lds` bytes of dynamic LDS, and the device's LDS per CU
+extern "C" int ctf_debug_step_occupancy(int lds, int* blocks_per_cu, int* lds_per_cu, int* lds_per_block) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    *lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    *lds_per_block = (int)prop.sharedMemPerBlock;
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_step<true, 4>, WAVE, (size_t)lds);
+}
+#endif
 static int obs_reserve_blocks() {
     static const int v = [] { const char* e = getenv("CTF_OBS_RESERVE_BLOCKS"); return e ? atoi(e) : 0; }();
     return v < 0 ? 0 : v;
