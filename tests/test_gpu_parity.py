@@ -100,6 +100,7 @@ def test_golden_trajectory(name):
 
 @pytest.mark.parametrize("name,n_envs,steps,log_metrics", [
     ("arena_random", 200, 160, True),     # partial last wave (200 = 3*64 + 8)
+    ("arena_random", 1300, 40, True),     # three tile groups of 512 envs, the last one ragged; 1 182 blocks padded to 1 184 for the XCD remap
     ("split_random", 4096, 64, True),     # BASELINE configs[1] size
     ("arena_stress", 130, 320, False),    # metrics compiled out, auto-reset crossing the episode end
     ("syn_axis1_drop", 96, 200, True),
@@ -109,8 +110,8 @@ def test_golden_trajectory(name):
 ])
 @pytest.mark.parametrize("tiles", [0, 1])
 def test_batch_matches_oracle(name, n_envs, steps, log_metrics, tiles, monkeypatch):
-    """``tiles``: the render as the wave-per-env kernel (k_observe) or as one-shot 4 KiB tiles (k_observe_tiles; taken
-    whenever an env's block is 16-byte aligned and >= 4 KiB, the wave-per-env kernel otherwise)."""
+    """``tiles``: the render as the wave-per-env kernel (k_observe) or as one-shot 8 KiB tiles (k_observe_tiles; taken
+    whenever an env's block is 16-byte aligned and >= 8 KiB, the wave-per-env kernel otherwise)."""
     monkeypatch.setenv("CTF_OBS_TILES", str(tiles))
     case = Case(name)
     auto_reset = name == "arena_stress"
