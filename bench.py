@@ -190,7 +190,7 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
                k_step_ms=float(step_all.mean()), k_observe_ms=float(obs_all.mean()),
                k_step_p=[float(x) for x in np.percentile(step_all, [10, 50, 90])],
                k_observe_p=[float(x) for x in np.percentile(obs_all, [10, 50, 90])],
-               placement_probe_ms=vec.placement_probe_ms, kwargs=kwargs)
+               placement_probe_ms=vec.placement_probe_ms, placement_fill_ms=vec.placement_fill_ms, kwargs=kwargs)
     if extras:
         # outside the timed region: the same env-step with the observation in compact form (ctf_observe_codes: one byte per
         # cell instead of C one-hot bytes — what the GPU policy path consumes)
@@ -328,6 +328,7 @@ def main():
             "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (r["k_step_ms"] * 1e-3) / 1e9,
             "episode_phase_spread": r.get("episode_phase_spread"),
             "placement_probe_ms": r["placement_probe_ms"],
+            "placement_fill_ms": r["placement_fill_ms"],
             "device_status_bits": r["status"],
             "ranks_seen": sorted(ranks_seen),
             "per_rank_ms_per_step": [per_rank_ms[ranks_seen.index(k)] for k in sorted(ranks_seen)],
