@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="$PWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-}"
+BENCH="$PWD/bench.py --steps 200 --warmup 20 --no-cpu-baseline ${BENCH_ARGS:-}"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $BENCH > $OUT/trace.log 2>&1 || echo "trace failed"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $BENCH > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed"
