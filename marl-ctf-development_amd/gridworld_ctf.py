@@ -124,8 +124,12 @@ class VecGridworldCtf:
                                          device=self.device)
         return self._codes
 
-    def _tune_obs_placement(self, tries=10, good_enough=1.10):
+    def _tune_obs_placement(self, tries=32, good_enough=1.10, memory_share=0.35):
         """Keep the candidate allocation the render streams into fastest (see __init__); frees the others.
+
+        Up to ``tries`` candidates, all held until the end (a freed one would simply be handed out again), but never more
+        than ``memory_share`` of the device memory that is free at the start: on some boxes only one allocation in twelve
+        is of the fast kind (tools/alloc_probe7.hip), and a probe costs about a millisecond.
 
         A candidate is good enough when the render into it takes at most ``good_enough`` x the time of a plain ``fill_`` of
         the same buffer (which does not depend on the buffer's kind): 1.03-1.10 on the fast kind, 1.12 / 1.25-1.3 on the
@@ -148,10 +152,12 @@ class VecGridworldCtf:
             return timed(lambda: self.observe(meta=False))
 
         best = self.obs
+        free_bytes, _ = torch.cuda.mem_get_info(self.device)
+        tries = max(1, min(int(tries), 1 + int(memory_share * free_bytes) // max(1, best.numel())))
         fill_ms = timed(lambda: best.fill_(0))
         best_ms, times = probe(best), []
         times.append(best_ms)
-        candidates = [best]  # rejected candidates stay allocated until the end, so that new ones land elsewhere
+        candidates, cand = [best], None  # rejected candidates stay allocated until the end, so that new ones land elsewhere
         for _ in range(tries - 1):
             if best_ms <= good_enough * fill_ms:
                 break
@@ -164,7 +170,10 @@ class VecGridworldCtf:
         self.obs = best
         self.placement_probe_ms = times
         self.placement_fill_ms = fill_ms
-        del candidates
+        n_held = len(candidates)
+        del candidates, cand
+        if n_held > 4:
+            torch.cuda.empty_cache()  # the rejected candidates go back to the driver instead of sitting in torch's cache
 
     # -- plumbing -----------------------------------------------------------------------------
     def _stream(self):
