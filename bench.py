@@ -152,14 +152,14 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     def one_step(t, events=None):
         if gather is not None:
             vec.rewards, vec.done = gather.views(t)
-        if events:
+        if events:  # a sampled step: the two launches apart, an event around each
             events[0].record()
-        vec.step(actions[t], auto_reset=True)
-        if events:
+            vec.step(actions[t], auto_reset=True)
             events[1].record()
-        vec.observe()
-        if events:
+            vec.observe()
             events[2].record()
+        else:       # the same two launches through one call of the C ABI (ctf_step_observe)
+            vec.step_observe(actions[t], auto_reset=True)
         if gather is not None:
             gather.step_done(t)  # closes a chunk every 16th step: issued after the render, it runs beside the next step kernel
 
