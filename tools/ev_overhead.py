@@ -1,5 +1,6 @@
+"""What do the HIP events that bench.py records around its launches cost?  The arena step with 3 / 2 / 1 / 0 event records per step."""
 import importlib, os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 pkg = importlib.import_module("marl-ctf-development_amd")
 kw = bench.WORKLOADS["arena"][1](pkg)
