@@ -508,6 +508,7 @@ __device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, co
     }
     uint32_t cap_mask = 0, resp_mask = 0, cap_team = 0;
 
+    STEP_STAMP(33);
     // Two shuffles per step: dice_roll (:734-742) before the agents act and the one inside heal_agents (:839-847)
     // after.  One rolled loop holds both so that the RNG refill code exists once.
 #pragma unroll 1

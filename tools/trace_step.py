@@ -63,13 +63,13 @@ print("blocks starting later than 20 us:", int(late.sum()))
 if os.environ.get('STEP_TRACE', '1') != '1':
     sys.exit(0)
 a = np.stack(acc)  # [steps, blocks, stamps]
-names = {0: "start", 1: "staged (loads -> LDS, barrier)", 2: "py refill 1", 3: "shuffle 1", 28: "py refill 2", 29: "shuffle 2", 30: "heal + rewards + vis log",
+names = {0: "start", 1: "staged (loads -> LDS, barrier)", 33: "prologue (positions, reset check, perm / flag bits)", 2: "py refill 1", 3: "shuffle 1", 28: "py refill 2", 29: "shuffle 2", 30: "heal + rewards + vis log",
          31: "flushes + rngpos", 32: "write-back issued"}
 for k in range(8):
     names[4 + 3 * k] = f"turn {k}: act"
     names[5 + 3 * k] = f"turn {k}: tagging"
     names[6 + 3 * k] = f"turn {k}: metrics"
-order = [0, 1, 2, 3] + [4 + i for i in range(24)] + [28, 29, 30, 31, 32]
+order = [0, 1, 33, 2, 3] + [4 + i for i in range(24)] + [28, 29, 30, 31, 32]
 prev = None
 tot = {}
 print("phase                                 mean us   p10    p90   (10 ns ticks of the 100 MHz clock, over steps x blocks)")
