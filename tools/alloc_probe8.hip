@@ -32,7 +32,9 @@ static float probe(uint8_t* buf, size_t bytes) {
 }
 int main() {
     const size_t bytes = (size_t)65536 * 25200;
-    const size_t sizes[] = {bytes, (size_t)2 << 30, (size_t)4 << 30, (size_t)8 << 30, bytes + (64 << 20)};  // every size >= bytes: the probe writes `bytes`
+    const size_t M = (size_t)1 << 20;
+    const size_t sizes[] = {bytes, (size_t)2 << 30, (size_t)4 << 30, bytes + 64 * M, bytes + 2 * M, bytes + 10 * M, bytes + 100 * M, bytes + 200 * M,
+                            bytes + 300 * M, ((size_t)2 << 30) - 2 * M, ((size_t)2 << 30) + 2 * M, (size_t)3 << 30};  // every size >= bytes: the probe writes `bytes`
     for (size_t sz : sizes) {
         std::vector<uint8_t*> keep;
         printf("size %6.3f GiB:", (double)sz / (1 << 30));
