@@ -124,7 +124,7 @@ class VecGridworldCtf:
                                          device=self.device)
         return self._codes
 
-    def _tune_obs_placement(self, tries=64, good_enough=1.10, memory_share=0.45):
+    def _tune_obs_placement(self, tries=64, good_enough=1.06, memory_share=0.45):
         """Keep the candidate allocation the render streams into fastest (see __init__); frees the others.
 
         Up to ``tries`` candidates, all held until the end (a freed one would simply be handed out again), but never more
@@ -132,8 +132,8 @@ class VecGridworldCtf:
         twenty-five is of the fast kind (tools/alloc_probe7.hip, alloc_probe8.hip), and a probe costs about a millisecond.
 
         A candidate is good enough when the render into it takes at most ``good_enough`` x the time of a plain ``fill_`` of
-        the same buffer (which does not depend on the buffer's kind): 1.03-1.10 on the fast kind, 1.12 / 1.25-1.3 on the
-        other two."""
+        the same buffer (which does not depend on the buffer's kind): 1.04-1.07 for the best buffers seen, 1.08-1.12 for an
+        intermediate kind, 1.2-1.3 for the slow one; searching on costs milliseconds, the best one is kept."""
         torch = _torch()
         stream = torch.cuda.current_stream(self.device)
 
