@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CTF_ABI_VERSION 1
+#define CTF_ABI_VERSION 2
 
 #define CTF_MAX_AGENTS 16   /* N  <= 16                                   */
 #define CTF_MAX_GRID 32     /* G  <= 32 (G*G <= 1024 cells)               */
@@ -46,6 +46,13 @@ extern "C" {
 #define CTF_ST_BAD_ACTION 1u   /* action outside 0..8: reference raises KeyError (gridworld_ctf.py:710) */
 #define CTF_ST_NO_RESPAWN 2u   /* no open cell round the spawn: np.random.randint(0) ValueError (:771)  */
 #define CTF_ST_SPAWN_EDGE 4u   /* respawn offset went negative (spawn on row/col 0, the WARNING at :773) */
+
+/* ctf_config.rng_mode */
+#define CTF_RNG_MT19937 0 /* the reference's two MT19937 generators, bit for bit (default)                          */
+#define CTF_RNG_COUNTER 1 /* opt-in: counter-based streams — word n of a stream = Philox4x32-10(key = the stream's
+                             seed, counter = (n / 4, stream, "CTF1"))[n % 4]; the draws are made from those words by the
+                             reference's own rules (random.shuffle, np.random.rand, np.random.randint): a reference run
+                             whose three functions read the same tape gives the same trajectory                     */
 
 /* ctf_step flags */
 #define CTF_STEP_AUTO_RESET 1u /* an env whose `done` is set is reset before it is stepped (not in the
@@ -86,7 +93,8 @@ typedef struct ctf_config {
     int32_t drop_flag_when_no_hp; /* DROP_FLAG_WHEN_NO_HP (:64)                                 */
     int32_t log_metrics;          /* 1 = keep counters + visitation maps (always on in the reference) */
     int32_t n_opponents[2];       /* len(OPPONENTS[t]) (:392-395)                               */
-    int32_t reserved0[6];         /* keeps the doubles 8-byte aligned without implicit padding */
+    int32_t rng_mode;             /* CTF_RNG_MT19937 (the reference's generators) or CTF_RNG_COUNTER */
+    int32_t reserved0[5];         /* keeps the doubles 8-byte aligned without implicit padding */
 
     double heal_per_step;         /* AGENT_HP_HEALING_PER_STEP (:212)                           */
     double tag_probability;       /* TAG_PROBABILITY (:231)                                     */
@@ -143,7 +151,10 @@ int64_t ctf_meta_elems_per_env(const ctf_env* env);
 
 /* Per-env twin MT19937 streams.  Env e behaves as a reference process after
  * `random.seed(py_seeds[e]); np.random.seed(np_seeds[e])` (CPython init_by_array / NumPy legacy
- * init_genrand).  Host arrays of n_envs seeds; np seeds must be < 2^32. */
+ * init_genrand).  Host arrays of n_envs seeds; np seeds must be < 2^32.
+ * (On the device a stream is kept as the ring of its NEXT 624 outputs, so that a step finds its random words in memory
+ * and regenerates behind itself; the hand-over functions below convert to and from the standard form, exactly.)
+ * In counter mode the seeds are the keys of the env's two counter streams (any 64-bit values), both at word 0. */
 int ctf_seed(ctf_env* env, const uint64_t* py_seeds, const uint64_t* np_seeds, void* stream);
 /* Exact state hand-over for one env: 624 words + position, i.e. random.getstate()[1] and
  * np.random.get_state()[1:3].  Either pointer may be NULL.  Synchronous. */
@@ -152,10 +163,15 @@ int ctf_get_rng_state(ctf_env* env, int32_t env_index, uint32_t* py_mt625, uint3
 
 /* The same for ALL envs at once, stream-ordered and without a device synchronisation: py_dev / np_dev are DEVICE arrays
  * uint32 [E][625] (624 state words + position per env, either may be NULL).  ctf_get_rng_states returns the standard
- * form (a lazily regenerated block is finished on the device).  What the facade's global-RNG contract uses per step
+ * form.  What the facade's global-RNG contract uses per step
  * (random.getstate() / np.random.get_state() in, the advanced states out) and what a checkpoint of a batch needs. */
 int ctf_set_rng_states(ctf_env* env, const uint32_t* py_dev, const uint32_t* np_dev, void* stream);
 int ctf_get_rng_states(ctf_env* env, uint32_t* py_dev, uint32_t* np_dev, void* stream);
+/* Counter mode only (the four functions above return CTF_E_INVALID there, these two in MT19937 mode): the whole RNG state
+ * of an env is how many words it has consumed from each stream.  counters_dev: DEVICE array uint64 [E][2] = (random,
+ * np.random).  Stream-ordered.  ctf_set_rng_counters is what a checkpoint restore calls after ctf_seed. */
+int ctf_get_rng_counters(ctf_env* env, uint64_t* counters_dev, void* stream);
+int ctf_set_rng_counters(ctf_env* env, const uint64_t* counters_dev, void* stream);
 
 /* GridworldCtf.reset() (gridworld_ctf.py:383-477) for the envs whose mask byte is non-zero
  * (NULL = all).  Draws no random numbers and keeps `_arr`, like the reference. */

@@ -6,7 +6,7 @@ entry point raises (``CtfLibraryError``) instead of routing anywhere else.
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_AGENTS = 16
 MAX_GRID = 32
 MAX_CELLS = MAX_GRID * MAX_GRID
@@ -19,6 +19,8 @@ ST_BAD_ACTION = 1
 ST_NO_RESPAWN = 2
 ST_SPAWN_EDGE = 4
 STEP_AUTO_RESET = 1
+RNG_MT19937 = 0
+RNG_COUNTER = 1
 REVERSE_DEFAULT = 0xFFFFFFFF
 
 # order of ctf_state_view.metrics rows == the reference's "agent_*" metric names (gridworld_ctf.py:456-468)
@@ -52,7 +54,8 @@ class CtfConfig(C.Structure):
         ("drop_flag_when_no_hp", C.c_int32),
         ("log_metrics", C.c_int32),
         ("n_opponents", C.c_int32 * 2),
-        ("reserved0", C.c_int32 * 6),
+        ("rng_mode", C.c_int32),
+        ("reserved0", C.c_int32 * 5),
         ("heal_per_step", C.c_double),
         ("tag_probability", C.c_double),
         ("guardian_damage_multiplier", C.c_double),
@@ -115,6 +118,8 @@ SYMBOLS = {
     "ctf_get_rng_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ctf_set_rng_states": (C.c_int, [_P, _P, _P, _P]),
     "ctf_get_rng_states": (C.c_int, [_P, _P, _P, _P]),
+    "ctf_get_rng_counters": (C.c_int, [_P, _P, _P]),
+    "ctf_set_rng_counters": (C.c_int, [_P, _P, _P]),
     "ctf_reset": (C.c_int, [_P, _P, _P]),
     "ctf_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_observe": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),

@@ -76,8 +76,9 @@ def opponents_of(agent_teams):
     }
 
 
-def build_config(kwargs, log_metrics=True):
-    """-> (CtfConfig, derived) where ``derived`` holds the host-side attributes of the reference env."""
+def build_config(kwargs, log_metrics=True, rng_mode=0):
+    """-> (CtfConfig, derived) where ``derived`` holds the host-side attributes of the reference env.
+    ``rng_mode``: _abi.RNG_MT19937 (the reference's two generators, default) or _abi.RNG_COUNTER (include/ctf_env.h)."""
     kw = dict(DEFAULT_KWARGS)
     unknown = set(kwargs) - set(kw)
     if unknown:
@@ -121,6 +122,7 @@ def build_config(kwargs, log_metrics=True):
     c.use_adjusted_rewards = int(bool(kw["USE_ADJUSTED_REWARDS"]))
     c.drop_flag_when_no_hp = int(bool(kw["DROP_FLAG_WHEN_NO_HP"]))
     c.log_metrics = int(bool(log_metrics))
+    c.rng_mode = int(rng_mode)
     for t in (0, 1):
         c.n_opponents[t] = len(opponents[t])
         for k, a in enumerate(opponents[t]):

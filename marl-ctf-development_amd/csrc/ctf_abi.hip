@@ -20,8 +20,10 @@ extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
-extern "C" hipError_t ctf_launch_import_rng(const DevCfg&, const DevPtrs&, const uint32_t*, const uint32_t*, hipStream_t);
-extern "C" hipError_t ctf_launch_export_rng(const DevCfg&, const DevPtrs&, uint32_t*, uint32_t*, hipStream_t);
+extern "C" hipError_t ctf_launch_import_rng(const DevCfg&, const DevPtrs&, const uint32_t*, const uint32_t*, int, int, hipStream_t);
+extern "C" hipError_t ctf_launch_export_rng(const DevCfg&, const DevPtrs&, uint32_t*, uint32_t*, int, int, hipStream_t);
+extern "C" hipError_t ctf_launch_get_counters(const DevCfg&, const DevPtrs&, unsigned long long*, hipStream_t);
+extern "C" hipError_t ctf_launch_set_counters(const DevCfg&, const DevPtrs&, const unsigned long long*, hipStream_t);
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
 
 struct ctf_env {
@@ -31,6 +33,7 @@ struct ctf_env {
     int device;
     int n_cus;
     uint64_t* seed_scratch;  // device, 2*E u64
+    uint32_t* rng_scratch;   // device, 2 x 625 u32: one env's two generators in the standard form (ctf_set/get_rng_state)
 };
 
 static thread_local char g_err[512] = "";
@@ -63,204 +66,14 @@ struct DeviceGuard {
     }
 };
 
-static int ceil_log2(uint32_t d) {
-    int l = 0;
-    while ((1u << l) < d) l++;
-    return l;
-}
-// Granlund-Montgomery round-up reciprocal, exact for every n < n_max (checked exhaustively)
-static bool make_fastdiv(uint32_t d, uint32_t n_max, FastDiv* out) {
-    int nbits = ceil_log2(n_max + 1);
-    if (nbits < 1) nbits = 1;
-    const int s = nbits + ceil_log2(d);
-    if (s > 62) return false;
-    const uint64_t m = ((1ull << s) + d - 1) / d;
-    if (m > 0xFFFFFFFFull) return false;
-    out->m = (uint32_t)m;
-    out->s = (uint32_t)s;
-    for (uint32_t n = 0; n < n_max; n++)
-        if ((uint32_t)(((uint64_t)n * out->m) >> out->s) != n / d) return false;
-    return true;
-}
-
-// the same reciprocal, needed (and checked) only for the multiples of `stride` below n_max
-static bool make_fastdiv_strided(uint32_t d, uint64_t n_max, uint32_t stride, FastDiv* out) {
-    int nbits = 1;
-    while ((1ull << nbits) < n_max + 1) nbits++;
-    const int s = nbits + ceil_log2(d);
-    if (s > 62) return false;
-    const uint64_t m = ((1ull << s) + d - 1) / d;
-    if (m > 0xFFFFFFFFull) return false;
-    out->m = (uint32_t)m;
-    out->s = (uint32_t)s;
-    for (uint64_t n = 0; n < n_max; n += stride)
-        if ((uint32_t)((n * out->m) >> out->s) != (uint32_t)(n / d)) return false;
-    return true;
-}
-static int gcd_int(int a, int b) { return b ? gcd_int(b, a % b) : a; }
-
-static int round_up(int x, int a) { return (x + a - 1) / a * a; }
-
-// Which of the env's distinct metadata values (mv[] of obs_build_env: 0 step fraction, 1 + t capture ratio for a viewer of
-// team t, 4 + j uint8-truncated hp of agent j, 20 + j has_flag[j], 40 = 1.0, 41 = 0.0) element k of viewer i's row shows
-// (gridworld_ctf.py:1044-1067) — the host twin of obs_meta_lut in ctf_kernels.hip, for the kernels that cannot afford to
-// rebuild the table per wave.
-static void host_meta_lut(const DevCfg& d, uint8_t* out) {
-    const int N = d.N, M = d.M;
-    for (int i = 0; i < N; i++)
-        for (int k = 0; k < M; k++) {
-            const int team = d.team[i];
-            int src = 41;
-            if (k == 0) src = 0;
-            else if (k == 1) src = 1 + team;
-            else if (k < 6) src = (k - 2 == d.type[i]) ? 40 : 41;
-            else {
-                int who = i;
-                if (k >= 8) {
-                    const int pidx = (k - 8) >> 1;
-                    const int n_own = d.n_opp[1 - team], n_op = d.n_opp[team];
-                    int self_idx = 15;
-                    for (int q = n_own - 1; q >= 0; q--)
-                        if (d.opp[1 - team][q] == i) self_idx = q;
-                    const int n_mates = n_own - (self_idx < n_own ? 1 : 0);
-                    if (pidx < n_mates) who = d.opp[1 - team][pidx + (pidx >= self_idx ? 1 : 0)];
-                    else if (pidx - n_mates < n_op) who = d.opp[team][pidx - n_mates];
-                    else who = -1;
-                }
-                if (who >= 0) src = ((k & 1) ? 20 : 4) + who;
-            }
-            out[i * M + k] = (uint8_t)src;
-        }
-}
-
-static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
-    memset(d, 0, sizeof(*d));
-    if (c->abi_version != CTF_ABI_VERSION) return fail(CTF_E_INVALID, "ctf_config.abi_version %d != %d", c->abi_version, CTF_ABI_VERSION);
-    if (n_envs < 1) return fail(CTF_E_INVALID, "n_envs must be >= 1");
-    const int N = c->n_agents, G = c->grid_size, C = c->n_channels;
-    if (N < 2 || N > CTF_MAX_AGENTS) return fail(CTF_E_INVALID, "n_agents %d outside 2..%d", N, CTF_MAX_AGENTS);
-    if (G < 4 || G > CTF_MAX_GRID) return fail(CTF_E_INVALID, "grid_size %d outside 4..%d", G, CTF_MAX_GRID);
-    if (C < 2 || C > 15) return fail(CTF_E_INVALID, "n_channels %d outside 2..15", C);
-    if (c->game_steps < 1) return fail(CTF_E_INVALID, "game_steps must be >= 1");
-    if (c->flip_axis < -1 || c->flip_axis > 2) return fail(CTF_E_INVALID, "flip_axis %d", c->flip_axis);
-    for (int t = 0; t < 2; t++) {
-        if (c->n_opponents[t] < 0 || c->n_opponents[t] > N) return fail(CTF_E_INVALID, "n_opponents[%d]", t);
-        for (int k = 0; k < c->n_opponents[t]; k++)
-            if (c->opponents[t][k] < 0 || c->opponents[t][k] >= N) return fail(CTF_E_INVALID, "opponents[%d][%d]", t, k);
-        const int8_t* pos[3] = {c->flag_pos[t], c->capture_pos[t], c->spawn_pos[t]};
-        for (int k = 0; k < 3; k++)
-            if (pos[k][0] < 0 || pos[k][0] >= G || pos[k][1] < 0 || pos[k][1] >= G) return fail(CTF_E_INVALID, "team %d position outside the grid", t);
-    }
-    for (int i = 0; i < N; i++) {
-        if (c->agent_team[i] < 0 || c->agent_team[i] > 1) return fail(CTF_E_INVALID, "agent_team[%d]", i);
-        if (c->agent_type[i] < 0 || c->agent_type[i] > 3) return fail(CTF_E_INVALID, "agent_type[%d]", i);
-        if (c->start_pos[i][0] < 0 || c->start_pos[i][0] >= G || c->start_pos[i][1] < 0 || c->start_pos[i][1] >= G)
-            return fail(CTF_E_INVALID, "start_pos[%d] outside the grid", i);
-        if (!(c->type_hp[c->agent_type[i]] > 0)) return fail(CTF_E_INVALID, "type_hp of agent %d must be > 0", i);
-    }
-    for (int k = 1; k < C; k++)
-        if (c->tile_of_channel[k] < 1 || c->tile_of_channel[k] > 13) return fail(CTF_E_INVALID, "tile_of_channel[%d]", k);
-    for (int k = 0; k < G * G; k++)
-        if (c->init_grid[k] > 13) return fail(CTF_E_INVALID, "init_grid[%d] = %d", k, c->init_grid[k]);
-
-    d->n_envs = n_envs; d->N = N; d->G = G; d->GG = G * G; d->C = C; d->M = 2 * N + 6;
-    d->game_steps = c->game_steps; d->flip_axis = c->flip_axis;
-    d->home_flag_capture = c->home_flag_capture; d->use_adjusted = c->use_adjusted_rewards;
-    d->drop_flag = c->drop_flag_when_no_hp; d->log_metrics = c->log_metrics ? 1 : 0;
-    d->n_opp[0] = c->n_opponents[0]; d->n_opp[1] = c->n_opponents[1];
-    d->GS = round_up(G * G, 16);
-    d->off_pos = 8 * N; d->off_flag = 10 * N; d->off_perm = 11 * N; d->off_inv = 12 * N;
-    d->off_misc = round_up(14 * N, 4);
-    d->RS = round_up(d->off_misc + 16, 16);
-    d->CGG = C * G * G; d->obs_bytes = N * d->CGG;
-    if (!make_fastdiv((uint32_t)d->CGG, (uint32_t)d->obs_bytes + 16, &d->div_cgg) ||
-        !make_fastdiv((uint32_t)d->GG, (uint32_t)d->CGG + 16, &d->div_gg) ||
-        !make_fastdiv((uint32_t)d->GG, (uint32_t)(N * d->GG) + 16, &d->div_gg_row) ||
-        !make_fastdiv((uint32_t)G, (uint32_t)d->GS + 4, &d->div_g) ||
-        !make_fastdiv((uint32_t)d->M, (uint32_t)(N * d->M) + 64, &d->div_m) ||
-        !make_fastdiv((uint32_t)N, (uint32_t)(256 * N) + 64, &d->div_n) ||
-        !make_fastdiv((uint32_t)(d->GS / 16), (uint32_t)(64 * d->GS / 16) + 64, &d->div_gq) ||
-        !make_fastdiv((uint32_t)(d->RS / 16), (uint32_t)(64 * d->RS / 16) + 64, &d->div_rq) ||
-        !make_fastdiv((uint32_t)(CTF_N_METRICS * N), (uint32_t)(64 * CTF_N_METRICS * N) + 64, &d->div_mn) ||
-        !make_fastdiv((uint32_t)((CTF_N_METRICS * N + 3) / 4), (uint32_t)(64 * ((CTF_N_METRICS * N + 3) / 4)) + 64, &d->div_mw))
-        return fail(CTF_E_INVALID, "internal: reciprocal division not exact for these dimensions");
-    d->tile_k = d->tile_tpg = 0;  // 0: no tile render for this configuration
-    if (d->obs_bytes % 16 == 0 && d->obs_bytes >= CTF_OBS_TILE) {
-        d->tile_k = CTF_OBS_TILE / gcd_int(d->obs_bytes, CTF_OBS_TILE);
-        d->tile_tpg = (int)((int64_t)d->tile_k * d->obs_bytes / CTF_OBS_TILE);
-        d->tile_bx = (d->tile_tpg + CTF_OBS_TILE_WPB - 1) / CTF_OBS_TILE_WPB;
-        const int64_t nb = ((int64_t)d->tile_bx * ((n_envs + d->tile_k - 1) / d->tile_k) + 7) / 8 * 8;
-        d->tile_nb = (int32_t)nb;
-        if (nb > 0x3FFFFFFF || !make_fastdiv((uint32_t)d->tile_bx, (uint32_t)nb + 8, &d->div_tile_bx) ||
-            !make_fastdiv_strided((uint32_t)d->obs_bytes, (uint64_t)d->tile_k * d->obs_bytes + CTF_OBS_TILE, CTF_OBS_TILE, &d->div_ob_tile))
-            d->tile_k = d->tile_tpg = d->tile_bx = d->tile_nb = 0;
-    }
-    if (const char* ov = getenv("CTF_STEP_W")) {
-        const int w = atoi(ov);
-        if (w == 1 || w == 2 || w == 4 || w == 8) d->step_lanes_override = w;
-    }
-    d->heal = c->heal_per_step; d->tag_p = c->tag_probability; d->guard_mult = c->guardian_damage_multiplier;
-    d->vault_cost = c->vault_hp_cost; d->vault_min = c->vault_min_hp;
-    d->r_capture = c->reward_capture; d->r_step = c->reward_step; d->r_tag = c->reward_tag;
-    d->win_scalar = c->win_margin_scalar; d->loss_scalar = c->loss_margin_scalar; d->punish = c->opp_capture_punishment;
-    for (int t = 0; t < 4; t++) { d->type_hp[t] = c->type_hp[t]; d->type_damage[t] = c->type_damage[t]; }
-    memcpy(d->team, c->agent_team, sizeof(d->team));
-    memcpy(d->type, c->agent_type, sizeof(d->type));
-    memcpy(d->opp, c->opponents, sizeof(d->opp));
-    memcpy(d->flag_pos, c->flag_pos, sizeof(d->flag_pos));
-    memcpy(d->capture_pos, c->capture_pos, sizeof(d->capture_pos));
-    memcpy(d->spawn_pos, c->spawn_pos, sizeof(d->spawn_pos));
-    memcpy(d->start_pos, c->start_pos, sizeof(d->start_pos));
-    for (int i = 0; i < N; i++) d->default_reverse |= (c->agent_team[i] == 1) ? (1 << i) : 0;
-    for (int i = 0; i < N; i++) {
-        d->team_mask |= (uint32_t)c->agent_team[i] << i;
-        d->type_pack |= (uint32_t)c->agent_type[i] << (2 * i);
-        uint64_t idx = 15;
-        const int own = 1 - c->agent_team[i];  // OPPONENTS[1 - team] is the agent's own team
-        for (int k = c->n_opponents[own] - 1; k >= 0; k--)
-            if (c->opponents[own][k] == i) idx = (uint64_t)k;
-        d->self_idx_pack |= idx << (4 * i);
-    }
-    for (int t = 0; t < 2; t++)
-        for (int k = 0; k < c->n_opponents[t]; k++) d->opp_pack[t] |= (uint64_t)c->opponents[t][k] << (4 * k);
-
-    // channel of every tile value as seen by a viewer of team t (reference gridworld_ctf.py:987-994: for a
-    // team-1 viewer own/opponent agent tiles 4..7 <-> 8..11 and the flags 12 <-> 13 swap), 15 = no plane
-    for (int t = 0; t < 2; t++) {
-        uint64_t lut = 0;
-        for (int v = 0; v < 16; v++) {
-            int std_tile = v;
-            if (t == 1) {
-                if (v >= 4 && v <= 7) std_tile = v + 4;
-                else if (v >= 8 && v <= 11) std_tile = v - 4;
-                else if (v == 12) std_tile = 13;
-                else if (v == 13) std_tile = 12;
-            }
-            uint64_t code = CTF_TILE_NONE;
-            if (v >= 1 && v <= 13)
-                for (int k = 1; k < C; k++)
-                    if (c->tile_of_channel[k] == std_tile) code = (uint64_t)k;
-            lut |= code << (4 * v);
-        }
-        d->chan_lut[t] = lut;
-    }
-    // metadata order (gridworld_ctf.py:1053-1067): own-team list minus self, then the opponents list
-    for (int i = 0; i < N; i++) {
-        int n = 0, team = c->agent_team[i];
-        for (int k = 0; k < CTF_MAX_AGENTS; k++) d->meta_order[i][k] = -1;
-        for (int k = 0; k < c->n_opponents[1 - team]; k++)
-            if (c->opponents[1 - team][k] != i && n < N - 1) d->meta_order[i][n++] = c->opponents[1 - team][k];
-        for (int k = 0; k < c->n_opponents[team]; k++)
-            if (n < N - 1) d->meta_order[i][n++] = c->opponents[team][k];
-    }
-    return CTF_OK;
-}
+#include "ctf_derive.h"
 
 static void free_all(ctf_env* h) {
     if (!h) return;
     (void)hipFree(h->p.grid); (void)hipFree(h->p.rec); (void)hipFree(h->p.mt_py); (void)hipFree(h->p.mt_np);
     (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis); (void)hipFree(h->p.vislog);
     (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
+    (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch);
     delete h;
 }
 
@@ -279,6 +92,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     if (!h) return fail(CTF_E_NOMEM, "host allocation failed");
     memset(&h->p, 0, sizeof(h->p));
     h->seed_scratch = nullptr;
+    h->rng_scratch = nullptr;
     h->cfg = *cfg; h->d = d; h->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
@@ -289,9 +103,11 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { free_all(h); return fail(CTF_E_NOMEM, "hipMalloc(%zu) failed", (size_t)(bytes)); }
     ALLOC(h->p.grid, E * d.GS);
     ALLOC(h->p.rec, E * d.RS);
-    ALLOC(h->p.mt_py, E * CTF_MT_N * 4);
-    ALLOC(h->p.mt_np, E * CTF_MT_N * 4);
+    ALLOC(h->p.mt_py, E * CTF_MT_STRIDE * 4);
+    ALLOC(h->p.mt_np, E * CTF_MT_STRIDE * 4);
     ALLOC(h->p.rngpos, E * 2 * 4);
+    ALLOC(h->p.rngctr, (d.rng_mode == CTF_RNG_COUNTER ? E * 4 : 1) * 8);
+    ALLOC(h->rng_scratch, 2 * (CTF_MT_N + 1) * 4);
     ALLOC(h->p.metrics, met_elems * 4);
     ALLOC(h->p.vis, vis_elems * 4);
     ALLOC(h->p.vislog, (d.log_metrics ? (size_t)CTF_VIS_LOG * E * d.N : 1) * 2);
@@ -342,8 +158,9 @@ extern "C" int ctf_seed(ctf_env* h, const uint64_t* py_seeds, const uint64_t* np
     if (!h || !py_seeds || !np_seeds) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
     const size_t E = (size_t)h->d.n_envs;
-    for (size_t e = 0; e < E; e++)
-        if (np_seeds[e] >> 32) return fail(CTF_E_INVALID, "np seed %zu must be < 2**32 (np.random.seed's own limit)", e);
+    if (h->d.rng_mode == CTF_RNG_MT19937)
+        for (size_t e = 0; e < E; e++)
+            if (np_seeds[e] >> 32) return fail(CTF_E_INVALID, "np seed %zu must be < 2**32 (np.random.seed's own limit)", e);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(h->seed_scratch, py_seeds, E * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(h->seed_scratch + E, np_seeds, E * 8, hipMemcpyHostToDevice, st));
@@ -352,48 +169,47 @@ extern "C" int ctf_seed(ctf_env* h, const uint64_t* py_seeds, const uint64_t* np
     return CTF_OK;
 }
 
-extern "C" int ctf_set_rng_state(ctf_env* h, int32_t e, const uint32_t* py, const uint32_t* np_) {
-    if (!h) return fail(CTF_E_INVALID, "null handle");
-    if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
-    DeviceGuard guard(h->device);
-    HIP_TRY(hipDeviceSynchronize());
-    const uint32_t* src[2] = {py, np_};
-    uint32_t* dst[2] = {h->p.mt_py, h->p.mt_np};
-    for (int k = 0; k < 2; k++) {
-        if (!src[k]) continue;
-        if (src[k][CTF_MT_N] > CTF_MT_N) return fail(CTF_E_INVALID, "MT position %u > 624", src[k][CTF_MT_N]);
-        HIP_TRY(hipMemcpy(dst[k] + (size_t)e * CTF_MT_N, src[k], CTF_MT_N * 4, hipMemcpyHostToDevice));
-        const uint32_t packed = src[k][CTF_MT_N];  // lazy flag clear: words [pos,624) are output as they stand
-        HIP_TRY(hipMemcpy(h->p.rngpos + 2 * (size_t)e + k, &packed, 4, hipMemcpyHostToDevice));
-    }
+static int need_mode(const ctf_env* h, int mode, const char* what) {
+    if (h->d.rng_mode != mode)
+        return fail(CTF_E_INVALID, "%s: the handle runs in %s mode", what, h->d.rng_mode == CTF_RNG_COUNTER ? "counter-RNG" : "MT19937");
     return CTF_OK;
 }
 
-// Brings a lazily regenerated block into the standard form (all 624 words of the current block).
-static void finish_block(uint32_t* a, uint32_t pos) {
-    for (uint32_t i = pos; i < CTF_MT_N; i++) {
-        const uint32_t i1 = (i + 1 == CTF_MT_N) ? 0u : i + 1;
-        const uint32_t im = (i + 397 >= CTF_MT_N) ? i + 397 - CTF_MT_N : i + 397;
-        const uint32_t y = (a[i] & 0x80000000u) | (a[i1] & 0x7fffffffu);
-        a[i] = a[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+extern "C" int ctf_set_rng_state(ctf_env* h, int32_t e, const uint32_t* py, const uint32_t* np_) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
+    if (int rc = need_mode(h, CTF_RNG_MT19937, "ctf_set_rng_state")) return rc;
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    const uint32_t* src[2] = {py, np_};
+    uint32_t* dev[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; k++) {
+        if (!src[k]) continue;
+        if (src[k][CTF_MT_N] > CTF_MT_N) return fail(CTF_E_INVALID, "MT position %u > 624", src[k][CTF_MT_N]);
+        dev[k] = h->rng_scratch + k * (CTF_MT_N + 1);
+        HIP_TRY(hipMemcpy(dev[k], src[k], (CTF_MT_N + 1) * 4, hipMemcpyHostToDevice));
     }
+    if (dev[0] || dev[1]) {
+        // the two records are not adjacent when only one is given: one launch per generator
+        if (dev[0]) HIP_TRY(ctf_launch_import_rng(h->d, h->p, dev[0], nullptr, e, 1, nullptr));
+        if (dev[1]) HIP_TRY(ctf_launch_import_rng(h->d, h->p, nullptr, dev[1], e, 1, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return CTF_OK;
 }
 
 extern "C" int ctf_get_rng_state(ctf_env* h, int32_t e, uint32_t* py, uint32_t* np_) {
     if (!h) return fail(CTF_E_INVALID, "null handle");
     if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
+    if (int rc = need_mode(h, CTF_RNG_MT19937, "ctf_get_rng_state")) return rc;
     DeviceGuard guard(h->device);
     HIP_TRY(hipDeviceSynchronize());
     uint32_t* dst[2] = {py, np_};
-    const uint32_t* src[2] = {h->p.mt_py, h->p.mt_np};
     for (int k = 0; k < 2; k++) {
         if (!dst[k]) continue;
-        uint32_t packed = 0;
-        HIP_TRY(hipMemcpy(dst[k], src[k] + (size_t)e * CTF_MT_N, CTF_MT_N * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&packed, h->p.rngpos + 2 * (size_t)e + k, 4, hipMemcpyDeviceToHost));
-        const uint32_t pos = packed & CTF_POS_MASK;
-        if (packed & CTF_LAZY_BIT) finish_block(dst[k], pos);
-        dst[k][CTF_MT_N] = pos;
+        uint32_t* dev = h->rng_scratch + k * (CTF_MT_N + 1);
+        HIP_TRY(ctf_launch_export_rng(h->d, h->p, k == 0 ? dev : nullptr, k == 1 ? dev : nullptr, e, 1, nullptr));
+        HIP_TRY(hipMemcpy(dst[k], dev, (CTF_MT_N + 1) * 4, hipMemcpyDeviceToHost));
     }
     return CTF_OK;
 }
@@ -401,16 +217,34 @@ extern "C" int ctf_get_rng_state(ctf_env* h, int32_t e, uint32_t* py, uint32_t* 
 extern "C" int ctf_set_rng_states(ctf_env* h, const uint32_t* py_dev, const uint32_t* np_dev, void* stream) {
     if (!h) return fail(CTF_E_INVALID, "null handle");
     if (!py_dev && !np_dev) return CTF_OK;
+    if (int rc = need_mode(h, CTF_RNG_MT19937, "ctf_set_rng_states")) return rc;
     DeviceGuard guard(h->device);
-    HIP_TRY(ctf_launch_import_rng(h->d, h->p, py_dev, np_dev, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_import_rng(h->d, h->p, py_dev, np_dev, 0, h->d.n_envs, (hipStream_t)stream));
     return CTF_OK;
 }
 
 extern "C" int ctf_get_rng_states(ctf_env* h, uint32_t* py_dev, uint32_t* np_dev, void* stream) {
     if (!h) return fail(CTF_E_INVALID, "null handle");
     if (!py_dev && !np_dev) return CTF_OK;
+    if (int rc = need_mode(h, CTF_RNG_MT19937, "ctf_get_rng_states")) return rc;
     DeviceGuard guard(h->device);
-    HIP_TRY(ctf_launch_export_rng(h->d, h->p, py_dev, np_dev, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_export_rng(h->d, h->p, py_dev, np_dev, 0, h->d.n_envs, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+extern "C" int ctf_get_rng_counters(ctf_env* h, uint64_t* counters_dev, void* stream) {
+    if (!h || !counters_dev) return fail(CTF_E_INVALID, "null argument");
+    if (int rc = need_mode(h, CTF_RNG_COUNTER, "ctf_get_rng_counters")) return rc;
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_get_counters(h->d, h->p, (unsigned long long*)counters_dev, (hipStream_t)stream));
+    return CTF_OK;
+}
+
+extern "C" int ctf_set_rng_counters(ctf_env* h, const uint64_t* counters_dev, void* stream) {
+    if (!h || !counters_dev) return fail(CTF_E_INVALID, "null argument");
+    if (int rc = need_mode(h, CTF_RNG_COUNTER, "ctf_set_rng_counters")) return rc;
+    DeviceGuard guard(h->device);
+    HIP_TRY(ctf_launch_set_counters(h->d, h->p, (const unsigned long long*)counters_dev, (hipStream_t)stream));
     return CTF_OK;
 }
 

@@ -7,9 +7,11 @@
 //   rec    u8  [E][RS]        one record per env, RS multiple of 16:
 //                               f64 hp[N] | i8 pos[N][2] | u8 has_flag[N] | u8 perm[N] | i16 inv[N]
 //                               | i32 step | i32 caps[2] | i32 flags (done, visitation log state)
-//   mt_py  u32 [E][624]       CPython `random` stream   (MT19937, lazily regenerated in place)
-//   mt_np  u32 [E][624]       NumPy legacy `np.random` stream
-//   rngpos u32 [E][2]         per stream: position (0..624) | lazy-flag << 16
+//   mt_py  u32 [E][CTF_MT_STRIDE]  CPython `random` stream: MT19937 in RUN-AHEAD form (ctf_mt.h) — the ring of the next 624
+//                                  raw outputs + a mirror of its first words + the saved old word 0
+//   mt_np  u32 [E][CTF_MT_STRIDE]  NumPy legacy `np.random` stream, same form
+//   rngpos u32 [E][2]         per stream: ring position (0..623) of the next output
+//   rngctr u64 [E][2]         counter mode only (cfg.rng_mode == 1): words consumed so far from each stream
 //   metric i32 [E][13][N]     agent-level counters (only when log_metrics)
 //   vislog u16 [512][E][N]    visitation LOG: entry (step % 512) = the cell of every agent after that step; the
 //                             maps are rebuilt from it on export, so a step writes 2N coalesced bytes per env
@@ -20,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/ctf_env.h"
+#include "ctf_mt.h"
 
 #define CTF_TILE_NONE 15u  // channel code of a tile that has no observation plane
 #ifndef CTF_OBS_TILE
@@ -43,6 +46,11 @@ struct DevCfg {
     FastDiv div_cgg, div_gg, div_g, div_m, div_n, div_gq, div_rq, div_mn, div_mw;
     FastDiv div_gg_row;             // / GG over 0 .. N*GG (the compact observation's rows)
     int32_t step_lanes_override;    // 0 = automatic; set from CTF_STEP_W for profiling
+    // np.random.rand() < TAG_PROBABILITY on the 53-bit integer x = (a >> 5) * 2^26 + (b >> 6): x < tag_thr, split at bit 26
+    uint32_t tag_th, tag_tl;
+    int32_t np_pairs;               // rand() draws of one step without respawns: sum over the agents that deal damage of their opponents
+    uint32_t dmg_mask;              // bit i = AGENT_TYPE_DAMAGE[type(i)] > 0
+    int32_t rng_mode;               // CTF_RNG_MT19937 / CTF_RNG_COUNTER
     // the tile render (k_observe_tiles): envs are taken in groups of tile_k, the smallest count whose blocks fill a whole
     // number (tile_tpg) of tiles; div_ob_tile divides a tile's byte offset inside its group (a multiple of the tile size) by obs_bytes
     int32_t tile_k, tile_tpg;
@@ -73,6 +81,7 @@ struct DevPtrs {
     uint32_t* mt_py;
     uint32_t* mt_np;
     uint32_t* rngpos;
+    unsigned long long* rngctr;  // counter mode: u64 [E][4] = words consumed (py, np), stream seeds (py, np)
     int32_t* metrics;
     uint32_t* vis;             // base maps u32 [E][N][GS]; valid only when the env's CTF_F_BASE_ZERO flag is clear
     uint16_t* vislog;          // u16 [CTF_VIS_LOG][E][N]
@@ -88,4 +97,3 @@ struct DevPtrs {
 #define CTF_F_FOLDED_SHIFT 2
 #define CTF_VIS_LOG 512
 #define CTF_POS_MASK 0xFFFFu
-#define CTF_LAZY_BIT 0x10000u

@@ -12,33 +12,13 @@
 #include <cstdlib>
 
 #include "ctf_device.h"
+#include "ctf_step_core.h"
 
 #define WAVE 64
 
 // ------------------------------------------------------------------------------------------------
-// small helpers
+// small helpers (fdiv, cheb, the SGPR-pinned config lookups, MT19937: ctf_step_core.h / ctf_mt.h)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (uint32_t)(((uint64_t)n * d.m) >> d.s); }
-__device__ __forceinline__ int iabs_(int x) { return x < 0 ? -x : x; }
-__device__ __forceinline__ int cheb(int r0, int c0, int r1, int c1) {
-    int a = iabs_(r0 - r1), b = iabs_(c0 - c1);
-    return a > b ? a : b;
-}
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
-
-// MT19937 with LAZY in-place regeneration (used by MtWin below): instead of rewriting all 624 words when
-// the block is exhausted (a 624-iteration burst that would serialise a divergent wave), word i of the
-// next block is produced from a[i], a[i+1], a[i+397] at the moment it is consumed.  Words [0,pos) then
-// belong to the new block and [pos,624) to the old one, which is exactly the order the standard in-place
-// algorithm visits them in, so the output stream is identical.  The lazy flag is 0 only between a state
-// import (words [pos,624) are output as they stand) and the first wrap.
-
 // NumPy npy_double_to_half: direct round-to-nearest-even f64 -> binary16 bits
 __device__ __forceinline__ uint16_t f64_to_f16(double d) {
     uint64_t b = (uint64_t)__double_as_longlong(d);
@@ -94,40 +74,55 @@ __device__ void mt_init_by_array(uint32_t* mt, const uint32_t* key, int len) {
     mt[0] = 0x80000000u;
 }
 
-// py_seeds / np_seeds: device arrays [E].  After this, env e == random.seed(py) ; np.random.seed(np).
+// the mirror of the ring's first words and the saved old word 0 (ctf_mt.h)
+__device__ void mt_finish_layout(uint32_t* a, uint32_t save0) {
+    for (int i = 0; i < CTF_MT_MIRROR; i++) a[CTF_MT_N + i] = a[i];
+    a[CTF_MT_SAVE] = save0;
+}
+// the ring of a counter-mode stream whose next word is word n: ring position 0 holds word n
+__device__ void ctr_fill_ring(uint32_t* a, unsigned long long seed, uint32_t stream, unsigned long long n) {
+    for (unsigned long long blk = n >> 2; (blk << 2) < n + CTF_MT_N; blk++) {
+        uint32_t o[4];
+        ctr_block(seed, blk, stream, o);
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long w = (blk << 2) + (unsigned long long)k;
+            if (w >= n && w < n + CTF_MT_N) a[(uint32_t)(w - n)] = o[k];
+        }
+    }
+    mt_finish_layout(a, 0u);
+}
+
+// py_seeds / np_seeds: device arrays [E].  After this, env e == random.seed(py) ; np.random.seed(np) (MT19937 mode), or its
+// two streams are the counter streams of these seeds from word 0 (counter mode).
 extern "C" __global__ void k_seed(DevCfg cfg, DevPtrs p, const uint64_t* py_seeds, const uint64_t* np_seeds) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.n_envs) return;
-    uint64_t ps = py_seeds[e];
-    uint32_t key[2] = {(uint32_t)ps, (uint32_t)(ps >> 32)};
-    mt_init_by_array(p.mt_py + (size_t)e * CTF_MT_N, key, key[1] ? 2 : 1);
-    mt_init_genrand(p.mt_np + (size_t)e * CTF_MT_N, (uint32_t)np_seeds[e]);
-    p.rngpos[2 * e + 0] = CTF_MT_N;  // both generators start exhausted: first draw regenerates
-    p.rngpos[2 * e + 1] = CTF_MT_N;
+    uint32_t* a_py = p.mt_py + (size_t)e * CTF_MT_STRIDE;
+    uint32_t* a_np = p.mt_np + (size_t)e * CTF_MT_STRIDE;
+    const uint64_t ps = py_seeds[e], ns = np_seeds[e];
+    if (cfg.rng_mode == CTF_RNG_COUNTER) {
+        ctr_fill_ring(a_py, ps, 0u, 0ull);
+        ctr_fill_ring(a_np, ns, 1u, 0ull);
+        unsigned long long* ctr = p.rngctr + 4 * (size_t)e;
+        ctr[0] = 0; ctr[1] = 0; ctr[2] = ps; ctr[3] = ns;
+    } else {
+        uint32_t key[2] = {(uint32_t)ps, (uint32_t)(ps >> 32)};
+        mt_init_by_array(a_py, key, key[1] ? 2 : 1);
+        mt_init_genrand(a_np, (uint32_t)ns);
+        // both generators start exhausted (position 624): the run-ahead ring is the whole first regenerated block
+        uint32_t sv;
+        mt_std_to_runahead(a_py, CTF_MT_N, &sv);
+        mt_finish_layout(a_py, sv);
+        mt_std_to_runahead(a_np, CTF_MT_N, &sv);
+        mt_finish_layout(a_np, sv);
+    }
+    p.rngpos[2 * e + 0] = 0;
+    p.rngpos[2 * e + 1] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // reset
 // ------------------------------------------------------------------------------------------------
-// Writes the reset record of one env at `sr` (any address space) — everything except `perm`.
-template <typename BytePtr>
-__device__ __forceinline__ void reset_record(const DevCfg& cfg, BytePtr sr) {
-    for (int i = 0; i < cfg.N; i++) {
-        uint64_t hb = (uint64_t)__double_as_longlong(cfg.type_hp[cfg.type[i]]);
-        ((uint32_t*)(sr))[2 * i] = (uint32_t)hb;
-        ((uint32_t*)(sr))[2 * i + 1] = (uint32_t)(hb >> 32);
-        sr[cfg.off_pos + 2 * i] = (uint8_t)cfg.start_pos[i][0];
-        sr[cfg.off_pos + 2 * i + 1] = (uint8_t)cfg.start_pos[i][1];
-        sr[cfg.off_flag + i] = 0;
-        *(uint16_t*)(sr + cfg.off_inv + 2 * i) = 0;
-    }
-    int32_t* misc = (int32_t*)(sr + cfg.off_misc);
-    misc[0] = 0;  // env_step_count
-    misc[1] = 0;  // team_flag_captures[0]
-    misc[2] = 0;  // team_flag_captures[1]
-    misc[3] = CTF_F_BASE_ZERO;  // not done; visitation = zero maps + the start cells (:473), log empty
-}
-
 // One 64-lane block per env; mask == nullptr resets every env.  init_perm is set only by ctf_create.
 extern "C" __global__ void __launch_bounds__(WAVE) k_reset(DevCfg cfg, DevPtrs p, const uint8_t* mask, int init_perm) {
     int e = blockIdx.x, lane = threadIdx.x;
@@ -149,594 +144,42 @@ extern "C" __global__ void __launch_bounds__(WAVE) k_reset(DevCfg cfg, DevPtrs p
 }
 
 // ------------------------------------------------------------------------------------------------
-// lane-divergent config lookups: bit-field extracts / selects on SGPR-resident values (no memory traffic)
-// ------------------------------------------------------------------------------------------------
-// pin*(): pass a kernel-argument value through an empty asm with an SGPR constraint so that it is an opaque SGPR value.  Without
-// this the compiler rewrites "team ? cfg.x[1] : cfg.x[0]" into ONE load from a lane-selected kernarg
-// address, i.e. a dependent vector-memory access in the middle of the per-agent loop.
-__device__ __forceinline__ int pin(int v) {
-    asm("" : "+s"(v));  // zero instructions: just makes the value an opaque SGPR operand
-    return v;
-}
-__device__ __forceinline__ uint64_t pin64(uint64_t v) {
-    asm("" : "+s"(v));
-    return v;
-}
-__device__ __forceinline__ double pind(double v) {
-    uint64_t b = (uint64_t)__double_as_longlong(v);
-    asm("" : "+s"(b));
-    return __longlong_as_double((long long)b);
-}
-__device__ __forceinline__ int cfg_team(const DevCfg& c, int a) { return (int)(((uint32_t)pin((int)c.team_mask) >> a) & 1u); }
-__device__ __forceinline__ int cfg_type(const DevCfg& c, int a) { return (int)(((uint32_t)pin((int)c.type_pack) >> (2 * a)) & 3u); }
-__device__ __forceinline__ int cfg_opp(const DevCfg& c, int team, int q) {
-    const uint64_t p0 = pin64(c.opp_pack[0]), p1 = pin64(c.opp_pack[1]);
-    return (int)(((team ? p1 : p0) >> (4 * q)) & 15u);
-}
-__device__ __forceinline__ int cfg_nopp(const DevCfg& c, int team) { return team ? pin(c.n_opp[1]) : pin(c.n_opp[0]); }
-__device__ __forceinline__ double sel4(const double* t, int k) {
-    const double t0 = pind(t[0]), t1 = pind(t[1]), t2 = pind(t[2]), t3 = pind(t[3]);
-    return k == 0 ? t0 : (k == 1 ? t1 : (k == 2 ? t2 : t3));
-}
-#define TSEL(arr, team, k) ((team) ? pin((int)(arr)[1][k]) : pin((int)(arr)[0][k]))
-
-// ------------------------------------------------------------------------------------------------
 // step — W lanes per env (W = 1, 2, 4 or 8 >= opponents per team), 64 / W envs per 64-thread block
 // ------------------------------------------------------------------------------------------------
 // The per-agent loop of GridworldCtf.step is inherently sequential (later agents see earlier agents' moves, tags and
 // respawns), so parallelism is across envs — but one lane per env leaves one wave per SIMD and a kernel bound by the
 // dependent LDS / VALU chain.  Here the W lanes of a group run the env's control flow redundantly (state reads are LDS
 // broadcasts; state WRITES are done by sub-lane 0 only) and split the work that is parallel inside an agent's turn:
-//   - tagging: sub-lane q draws the np.random.rand() of opponent q from its own two window words and tests range;
-//     __ballot finds the first hit, which is applied (possibly respawning, which consumes extra words) before the
-//     remaining opponents are re-evaluated from the shifted stream position — exactly the reference's draw order;
+//   - tagging: every lane holds the rand() < TAG_PROBABILITY bits of its share of the step's np.random window and evaluates
+//     one opponent; __ballot finds the first hit, which is applied (possibly respawning, which consumes extra words) before
+//     the remaining opponents are re-evaluated from the shifted stream position — exactly the reference's draw order;
 //   - adjacency / zone metrics, healing, rewards, visitation: one agent per sub-lane;
-//   - MT window refills and write-backs: one word per sub-lane per pass.
+//   - the random words of the step (loads, tempering, threshold tests) and their replacement at the end.
 // 64 / W envs per wave means W times more waves (4 per SIMD for the arena) to hide the latency chain.
+// The logic itself — env_step, the two streams, group_step / group_finish — is ctf_step_core.h.
 //
-// LDS slot of one env (bytes):
-//   [grid GS][rec RS][actions 16][py window 64][np window 64][metric deltas u8 13*N (METRICS)]
-// The slot stride in dwords is odd so that different groups' same-offset accesses fall in distinct banks.
-#ifndef WCAP
-#define WCAP 16  // MT words per window (>= 2 * max opponents per team)
-#endif
-// Profiling-only ablations of the step kernel (results become wrong; never defined in the shipped build):
-//   bit0 no tagging, bit1 no metric section, bit2 no shuffles, bit3 no act, bit4 no visitation atomics,
-//   bit5 no metric flush, bit6 no state write-back, bit7 MT refills without their loads, bit8 MT flushes without their stores
-#ifndef STEP_ABLATE
-#define STEP_ABLATE 0
-#endif
-// Profiling-only phase trace of the step kernel (tools/trace_step.py): lane 0 of every block stamps the 100 MHz
-// wall clock at fixed points of the step (1: every phase, 2: start / end only); never defined in the shipped build.
+// Profiling-only phase trace (tools/trace_step.py): lane 0 of every block stamps the 100 MHz wall clock at fixed points
+// (0 start, 1 staged, 2 stepped, 3 written back, 4 end); never defined in the shipped build.
 #ifndef STEP_TRACE
 #define STEP_TRACE 0
 #endif
 #if STEP_TRACE
-__device__ unsigned long long g_step_trace[8192][40];
-__device__ unsigned long long g_step_span[8192][3];  // every block: start, end, HW_ID
-#define STEP_STAMP(k) do { if (threadIdx.x == 0 && (STEP_TRACE == 1 || (k) == 0 || (k) == 32)) { const unsigned long long t_ = wall_clock64(); \
-        if (STEP_TRACE == 1 && blockIdx.x < 8192) g_step_trace[blockIdx.x][(k)] = t_; \
-        if ((k) == 0 && blockIdx.x < 8192) { g_step_span[blockIdx.x][0] = t_; g_step_span[blockIdx.x][2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); } \
-        if ((k) == 32 && blockIdx.x < 8192) g_step_span[blockIdx.x][1] = t_; } } while (0)
+__device__ unsigned long long g_step_trace[8192][8];
+#define STEP_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_step_trace[blockIdx.x][(k)] = wall_clock64(); } while (0)
 extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_trace), sizeof(g_step_trace));
-}
-extern "C" int ctf_debug_step_span(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_span), sizeof(g_step_span));
 }
 #else
 #define STEP_STAMP(k) do { } while (0)
 #endif
 
-__host__ __device__ inline int step_slot_bytes(int GS, int RS, int N, bool metrics) {
-    int b = GS + RS + 16 + 2 * WCAP * 4 + (metrics ? ((CTF_N_METRICS * N + 3) & ~3) : 0);
-    if (((b / 4) & 1) == 0) b += 4;
-    return b;
-}
-
-// One MT19937 stream of one env: state words in HBM, a WCAP-word window of the next words in LDS (untempered, already
-// regenerated).  All fields are replicated in the registers of the group's W lanes and updated identically.
-// Lazy in-place regeneration (see above); a window may span the end of a block: word idx >= 624 is word idx-624 of
-// the next block and is always regenerated.
-struct MtWin {
-    uint32_t* a;    // 624 state words (global)
-    uint32_t* win;  // WCAP words (LDS)
-    uint32_t pos;   // stream position of win[0], 0..624
-    uint32_t lazy;
-    uint32_t n, cur;
-};
-__device__ __forceinline__ MtWin mtw_open(uint32_t* base, uint32_t* win, uint32_t packed) {
-    MtWin g;
-    g.a = base; g.win = win;
-    g.pos = packed & CTF_POS_MASK;
-    g.lazy = (packed & CTF_LAZY_BIT) ? 1u : 0u;
-    g.n = 0; g.cur = 0;
-    return g;
-}
-// ---- the window's traffic with the state array.  Sub-lane j of the group owns the T = WCAP / W CONSECUTIVE window words
-// [T j, T j + T): its state words are one (4-byte aligned) multi-dword access, so that a group reads / writes whole 64-byte
-// runs instead of 16-byte pieces — the MT streams are 40 % of the step kernel's time, all of it memory requests.
-typedef uint32_t mt_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t mt_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-// words a[i0 .. i0 + T) with indices taken modulo 624 (i0 < 624)
-template <int T>
-__device__ __forceinline__ void mt_load_span(const uint32_t* a, uint32_t i0, uint32_t* out) {
-    if (i0 + T <= CTF_MT_N) {
-        if constexpr (T % 4 == 0) {
-#pragma unroll
-            for (int q = 0; q < T / 4; q++) {
-                const mt_u32x4 v = *(const mt_u32x4*)(a + i0 + 4 * q);
-                out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
-            }
-        } else if constexpr (T == 2) {
-            const mt_u32x2 v = *(const mt_u32x2*)(a + i0);
-            out[0] = v.x; out[1] = v.y;
-        } else {
-#pragma unroll
-            for (int k = 0; k < T; k++) out[k] = a[i0 + k];
-        }
-    } else {  // the span crosses the end of the block
-#pragma unroll
-        for (int k = 0; k < T; k++) out[k] = a[i0 + k >= CTF_MT_N ? i0 + k - CTF_MT_N : i0 + k];
-    }
-}
-// stores the consumed, regenerated words of the window (words [0, cur)) back to the state array
-template <int W>
-__device__ __forceinline__ void mtw_store_consumed(const MtWin& g, int j) {
-    constexpr int T = WCAP / W;
-    if (STEP_ABLATE & 256) return;  // no flush stores
-    const int c = (int)g.cur - T * j;  // how many of this lane's words were consumed
-    if (c <= 0) return;
-    const uint32_t idx0 = g.pos + (uint32_t)(T * j);
-    const bool crossing = idx0 < CTF_MT_N && idx0 + T > CTF_MT_N;
-    if (T % 4 == 0 && c >= T && !crossing && (g.lazy || idx0 >= CTF_MT_N)) {
-        uint32_t* dst = g.a + (idx0 >= CTF_MT_N ? idx0 - CTF_MT_N : idx0);
-#pragma unroll
-        for (int q = 0; q < T / 4; q++) {
-            const mt_u32x4 v = {g.win[T * j + 4 * q], g.win[T * j + 4 * q + 1], g.win[T * j + 4 * q + 2], g.win[T * j + 4 * q + 3]};
-            *(mt_u32x4*)(dst + 4 * q) = v;
-        }
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < T; k++) {
-        const uint32_t idx = idx0 + (uint32_t)k;
-        const bool wrapped = idx >= CTF_MT_N;
-        if (k < c && (g.lazy | (uint32_t)wrapped)) g.a[wrapped ? idx - CTF_MT_N : idx] = g.win[T * j + k];
-    }
-}
-// write the consumed words back and advance; unconsumed window words are simply dropped — they are recomputed from
-// unchanged state words by the next refill
-template <int W>
-__device__ __forceinline__ void mtw_flush(MtWin& g, int j) {
-    mtw_store_consumed<W>(g, j);
-    g.pos += g.cur;
-    if (g.pos > CTF_MT_N) { g.pos -= CTF_MT_N; g.lazy = 1; }
-    g.n = 0; g.cur = 0;
-}
-// flush + refill in one: the NEW window's loads are issued first, then the consumed words of the old window are stored, then
-// the new window is written.  The words loaded are never among the words stored: the loads touch [npos, npos + WCAP], their
-// + 397 partners and, beyond 227, words regenerated >= 211 positions ago; the stores [npos - cur, npos).
-template <int W>
-__device__ __forceinline__ void mtw_cycle(MtWin& g, int j, int gshift) {
-    constexpr int T = WCAP / W;
-    uint32_t npos = g.pos + g.cur, nlazy = g.lazy;
-    if (npos > CTF_MT_N) { npos -= CTF_MT_N; nlazy = 1; }
-    const uint32_t idx0 = npos + (uint32_t)(T * j);                       // stream index of this lane's first word
-    const uint32_t i0 = idx0 >= CTF_MT_N ? idx0 - CTF_MT_N : idx0;        // ... as a state word
-    uint32_t x0[T], x1n, m[T];
-    if (STEP_ABLATE & 128) {  // no refill loads
-#pragma unroll
-        for (int k = 0; k < T; k++) { x0[k] = (i0 + k) * 2654435761u; m[k] = x0[k] >> 3; }
-        x1n = x0[0] ^ 0x55u;
-    } else {
-        mt_load_span<T>(g.a, i0, x0);
-        mt_load_span<T>(g.a, i0 + 397 >= CTF_MT_N ? i0 + 397 - CTF_MT_N : i0 + 397, m);
-        // a[i + 1] of the lane's last word = the next lane's first word; the group's last lane loads it
-        const uint32_t inext = i0 + T >= CTF_MT_N ? i0 + T - CTF_MT_N : i0 + T;
-        x1n = (j == W - 1) ? g.a[inext] : 0u;
-    }
-    mtw_store_consumed<W>(g, j);  // the old window's consumed, regenerated words go back (LDS reads -> global stores)
-    if (W > 1) {
-        const uint32_t from_next = (uint32_t)__shfl((int)x0[0], gshift + ((j + 1) & (W - 1)), WAVE);
-        if (j != W - 1) x1n = from_next;
-    }
-#pragma unroll
-    for (int k = 0; k < T; k++) {
-        const uint32_t idx = idx0 + (uint32_t)k;
-        const bool lz = (nlazy | (uint32_t)(idx >= CTF_MT_N)) != 0;
-        const uint32_t nx = (k + 1 < T) ? x0[k + 1 < T ? k + 1 : 0] : x1n;
-        const uint32_t y = (x0[k] & 0x80000000u) | (nx & 0x7fffffffu);
-        const uint32_t v = m[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        g.win[T * j + k] = lz ? v : x0[k];
-    }
-    g.pos = npos; g.lazy = nlazy;
-    g.n = WCAP; g.cur = 0;
-}
-// make sure `need` (<= WCAP) words are in the window; group-uniform, so the W lanes refill together
-template <int W>
-__device__ __forceinline__ void mtw_ensure(MtWin& g, int j, int gshift, uint32_t need) {
-    if (g.n - g.cur < need) mtw_cycle<W>(g, j, gshift);
-}
-template <int W>
-__device__ __forceinline__ uint32_t mtw_next(MtWin& g, int j, int gshift) {
-    mtw_ensure<W>(g, j, gshift, 1);
-    return mt_temper(g.win[g.cur++]);
-}
-// CPython random._randbelow_with_getrandbits(n): k = n.bit_length(); draw k bits until < n.
-// The W lanes of the group look at the next W words of the stream at once (sub-lane q at word cur + q): the first accepted
-// one is the draw and everything up to it is consumed — the same words in the same order as the one-word-at-a-time loop, in
-// ~1.3 rounds instead of the ~5 that the slowest of a wave's 16 groups needs when the acceptance probability is 1/2.
-template <int W>
-__device__ __forceinline__ uint32_t py_randbelow(MtWin& g, int j, int gshift, uint32_t n) {
-    const uint32_t sh = (uint32_t)__clz((int)n);
-    if (W == 1) {
-        uint32_t r;
-        do { r = mtw_next<W>(g, j, gshift) >> sh; } while (r >= n);
-        return r;
-    }
-    for (;;) {
-        mtw_ensure<W>(g, j, gshift, (uint32_t)W);
-        const uint32_t r = mt_temper(g.win[g.cur + j]) >> sh;
-        const uint32_t ok = (uint32_t)(__ballot(r < n) >> gshift) & ((1u << W) - 1u);
-        if (ok) {
-            const int first = __ffs((int)ok) - 1;
-            g.cur += (uint32_t)first + 1u;
-            return (uint32_t)__shfl((int)r, gshift + first, WAVE);
-        }
-        g.cur += W;
-    }
-}
-// NumPy legacy randint(k), k >= 1: masked rejection on one 32-bit word; k == 1 draws nothing
-template <int W>
-__device__ __forceinline__ uint32_t np_randint(MtWin& g, int j, int gshift, uint32_t k) {
-    const uint32_t rng = k - 1;
-    if (rng == 0) return 0;
-    const uint32_t mask = 0xFFFFFFFFu >> __clz((int)rng);
-    uint32_t v;
-    do { v = mtw_next<W>(g, j, gshift) & mask; } while (v > rng);
-    return v;
-}
-
-template <int W>
-struct StepCtx {
-    uint8_t* sg;   // grid  (LDS)
-    uint8_t* sr;   // record (LDS)
-    uint8_t* sm;   // metric deltas of this step (LDS) or nullptr
-    int j;         // sub-lane within the env's group
-    int gshift;    // first lane of the group
-    bool lead;     // j == 0: performs the state writes
-    __device__ __forceinline__ uint32_t ballot(bool p) const {
-        return (uint32_t)(__ballot(p) >> gshift) & ((1u << W) - 1u);
-    }
-};
-
-template <int W>
-__device__ __forceinline__ double ld_hp(const StepCtx<W>& s, int a) {
-    const uint32_t* q = (const uint32_t*)(s.sr + 8 * a);
-    return __hiloint2double((int)q[1], (int)q[0]);
-}
-template <int W>
-__device__ __forceinline__ void st_hp(const StepCtx<W>& s, int a, double v) {
-    uint32_t* q = (uint32_t*)(s.sr + 8 * a);
-    q[0] = (uint32_t)__double2loint(v);
-    q[1] = (uint32_t)__double2hiint(v);
-}
+// 16 blocks (= waves) per CU fit by LDS: the register budget is held to the matching 4 waves per SIMD (128 VGPRs)
 template <bool METRICS, int W>
-__device__ __forceinline__ void metric_add(const DevCfg& cfg, const StepCtx<W>& s, int m, int a, int v) {
-    if (METRICS && s.lead) s.sm[m * cfg.N + a] += (uint8_t)v;  // per-step deltas stay far below 256
-}
-// a counter that agent a's turn touches exactly once per step: a plain store instead of an LDS read-modify-write (the deltas
-// start the step at zero), so that consecutive updates do not wait for each other's reads
-template <bool METRICS, int W>
-__device__ __forceinline__ void metric_set(const DevCfg& cfg, const StepCtx<W>& s, int m, int a, int v) {
-    if (METRICS && s.lead) s.sm[m * cfg.N + a] = (uint8_t)v;
-}
-
-// respawn, gridworld_ctf.py:761-794 (all lanes of the group compute; sub-lane 0 writes)
-template <int W>
-__device__ __forceinline__ void respawn(const DevCfg& cfg, const StepCtx<W>& s, MtWin& np_, int o, uint32_t& flagm, uint32_t& status) {
-    const int G = cfg.G, team = cfg_team(cfg, o), type = cfg_type(cfg, o);
-    const int x = TSEL(cfg.spawn_pos, team, 0), y = TSEL(cfg.spawn_pos, team, 1);
-    const int r0 = x - 1 > 0 ? x - 1 : 0, c0 = y - 1 > 0 ? y - 1 : 0;
-    const int r1 = x + 2 < G ? x + 2 : G, c1 = y + 2 < G ? y + 2 : G;
-    // open cells of the (clipped) 3x3 window as a bitmask in row-major candidate order
-    uint32_t open = 0;
-    int k = 0;
-    for (int r = r0; r < r1; r++)
-        for (int c = c0; c < c1; c++)
-            if (s.sg[r * G + c] == 0) { open |= 1u << ((r - r0) * 3 + (c - c0)); k++; }
-    if (k == 0) { status |= CTF_ST_NO_RESPAWN; return; }
-    const uint32_t rnd = np_randint<W>(np_, s.j, s.gshift, (uint32_t)k);
-    uint32_t bits = open;
-    for (uint32_t t = 0; t < rnd; t++) bits &= bits - 1;  // drop the rnd lowest candidates
-    const int sel = __ffs((int)bits) - 1;
-    int nr = x + sel / 3 - 1, nc = y + sel % 3 - 1;  // "-1" even when the window was clipped (:775)
-    if (nr < 0 || nc < 0) { status |= CTF_ST_SPAWN_EDGE; nr = nr < 0 ? nr + G : nr; nc = nc < 0 ? nc + G : nc; }
-    int8_t* ps = (int8_t*)(s.sr + cfg.off_pos);
-    const int orow = ps[2 * o], ocol = ps[2 * o + 1];
-    const bool carrying = (flagm >> o) & 1u;
-    if (s.lead) {
-        s.sg[orow * G + ocol] = 0;
-        s.sg[nr * G + nc] = (uint8_t)(4 + type + 4 * team);
-        ps[2 * o] = (int8_t)nr;
-        ps[2 * o + 1] = (int8_t)nc;
-        st_hp(s, o, sel4(cfg.type_hp, type));
-        if (carrying) {
-            if (cfg.drop_flag) s.sg[orow * G + ocol] = (uint8_t)(12 + (1 - team));
-            else s.sg[TSEL(cfg.flag_pos, 1 - team, 0) * G + TSEL(cfg.flag_pos, 1 - team, 1)] = (uint8_t)(12 + (1 - team));
-        }
-    }
-    flagm &= ~(1u << o);
-}
-
-// GridworldCtf.step for ONE env (state in LDS), executed by the W lanes of its group.
-template <bool METRICS, int W>
-__device__ __forceinline__ void env_step(const DevCfg& cfg, const DevPtrs& p, const StepCtx<W>& s, const int8_t* act, MtWin& py,
-                                         MtWin& np_, uint32_t& status, int e, float* __restrict__ rw32, double* __restrict__ rw64,
-                                         uint8_t* __restrict__ done_out) {
-    const int N = cfg.N, G = cfg.G, j = s.j;
-    int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
-    int8_t* ps = (int8_t*)(s.sr + cfg.off_pos);
-    int16_t* inv = (int16_t*)(s.sr + cfg.off_inv);
-
-    // replicated register copies of the small per-env state: step, captures, has_flag bits, _arr as nibbles
-    const int step = misc[0] + 1;
-    int caps[2] = {misc[1], misc[2]};
-    int vis_flags = misc[3];
-    if (METRICS && (step - 1) - (vis_flags >> CTF_F_FOLDED_SHIFT) >= CTF_VIS_LOG - 1) {
-        // the env went 511 steps without a reset: fold its log into the base maps before entry `step` reuses a slot
-        uint32_t* base = p.vis + (size_t)e * N * cfg.GS;
-        if (vis_flags & CTF_F_BASE_ZERO) {
-            for (int w = j; w < N * cfg.GS; w += W) base[w] = 0;
-            __builtin_amdgcn_s_waitcnt(0);
-            for (int i = j; i < N; i += W) atomicAdd(base + i * cfg.GS + cfg.start_pos[i][0] * G + cfg.start_pos[i][1], 1u);
-        }
-        for (int st = (vis_flags >> CTF_F_FOLDED_SHIFT) + 1; st <= step - 1; st++)
-            for (int i = j; i < N; i += W)
-                atomicAdd(base + i * cfg.GS + p.vislog[((size_t)(st & (CTF_VIS_LOG - 1)) * cfg.n_envs + e) * N + i], 1u);
-        vis_flags = (vis_flags & CTF_F_DONE) | ((step - 1) << CTF_F_FOLDED_SHIFT);
-    }
-    uint32_t flagm = 0;
-    uint64_t perm = 0;
-#pragma unroll
-    for (int i = 0; i < CTF_MAX_AGENTS; i++) {
-        if (i < N) {
-            flagm |= (uint32_t)(s.sr[cfg.off_flag + i] & 1u) << i;
-            perm |= (uint64_t)(s.sr[cfg.off_perm + i] & 15u) << (4 * i);
-        }
-    }
-    uint32_t cap_mask = 0, resp_mask = 0, cap_team = 0;
-
-    STEP_STAMP(33);
-    // Two shuffles per step: dice_roll (:734-742) before the agents act and the one inside heal_agents (:839-847)
-    // after.  One rolled loop holds both so that the RNG refill code exists once.
-#pragma unroll 1
-    for (int phase = 0; phase < 2; phase++) {
-        // top the CPython window up while the whole wave is at the same point (rejection sampling lets the groups'
-        // stream positions diverge; refilling on demand would re-run the refill per group)
-        if (!(STEP_ABLATE & 4)) mtw_cycle<W>(py, j, s.gshift);
-        STEP_STAMP(phase == 0 ? 2 : 28);
-#pragma unroll 1
-        for (int i = (STEP_ABLATE & 4) ? 0 : N - 1; i >= 1; i--) {  // random.shuffle(self._arr)
-            const uint32_t r = py_randbelow<W>(py, j, s.gshift, (uint32_t)i + 1u);
-            const uint64_t vi = (perm >> (4 * i)) & 15u, vr = (perm >> (4 * r)) & 15u;
-            perm = (perm & ~((uint64_t)15u << (4 * i)) & ~((uint64_t)15u << (4 * r))) | (vr << (4 * i)) | (vi << (4 * r));
-        }
-        STEP_STAMP(phase == 0 ? 3 : 29);
-        if (phase == 1) break;
-
-#pragma unroll 1
-        for (int k = 0; k < N; k++) {
-            const int a = (int)((perm >> (4 * k)) & 15u);
-            const int type = cfg_type(cfg, a), team = cfg_team(cfg, a);
-            int action = act[a];
-            if (action < 0 || action >= CTF_N_ACTIONS) { status |= CTF_ST_BAD_ACTION; action = 4; }
-
-            // ---- act (:700-732); ACTION_DELTAS (:100-145): vaulter jumps 2, miner acts at distance 1 on 5..8
-            const int base = action <= 4 ? action : action - 5;
-            const int scale = action <= 4 ? 1 : (type == 2 ? 2 : (type == 3 ? 1 : 0));
-            const int dr = (base == 0 ? -1 : (base == 1 ? 1 : 0)) * scale;
-            const int dc = (base == 2 ? 1 : (base == 3 ? -1 : 0)) * scale;
-            int pr = ps[2 * a], pc = ps[2 * a + 1];
-            const int nr = pr + dr, nc = pc + dc;
-            if (!(STEP_ABLATE & 8) && nr >= 0 && nr < G && nc >= 0 && nc < G) {
-                const int cell = s.sg[nr * G + nc];
-                if (cell == 0 && (action <= 3 || (action >= 5 && type == 2 && (ld_hp(s, a) - cfg.vault_cost) > cfg.vault_min))) {
-                    // movement_handler (:569-612)
-                    const int ofr = TSEL(cfg.flag_pos, 1 - team, 0), ofc = TSEL(cfg.flag_pos, 1 - team, 1);
-                    const int hfr = TSEL(cfg.flag_pos, team, 0), hfc = TSEL(cfg.flag_pos, team, 1);
-                    const int opp_flag_cell = s.sg[ofr * G + ofc], home_flag_cell = s.sg[hfr * G + hfc];  // neither is the moved-from / moved-to cell
-                    if (s.lead) {
-                        s.sg[pr * G + pc] = 0;
-                        s.sg[nr * G + nc] = (uint8_t)(4 + type + 4 * team);
-                        ps[2 * a] = (int8_t)nr;
-                        ps[2 * a + 1] = (int8_t)nc;
-                    }
-                    pr = nr; pc = nc;
-                    if (cheb(nr, nc, ofr, ofc) <= 1 && opp_flag_cell == 12 + (1 - team)) {  // pickup: flag cell -> BLOCK
-                        flagm |= 1u << a;
-                        if (s.lead) s.sg[ofr * G + ofc] = 1;
-                        metric_add<METRICS>(cfg, s, CTF_M_FLAG_PICKUPS, a, 1);
-                    }
-                    if (cheb(nr, nc, hfr, hfc) <= 1 && ((flagm >> a) & 1u)) {  // capture
-                        if (!cfg.home_flag_capture || home_flag_cell == 12 + team) {
-                            flagm &= ~(1u << a);
-                            if (s.lead) s.sg[ofr * G + ofc] = (uint8_t)(12 + (1 - team));
-                            caps[0] += team == 0;
-                            caps[1] += team == 1;
-                            metric_add<METRICS>(cfg, s, CTF_M_FLAG_CAPTURES, a, 1);
-                            cap_mask |= 1u << a;
-                            cap_team |= 1u << team;
-                        }
-                    }
-                    if (action >= 5 && type == 2) {  // update_vaulter_hp
-                        const double h = ld_hp(s, a) - cfg.vault_cost;
-                        if (s.lead) st_hp(s, a, h);
-                    }
-                } else if (action >= 5 && type == 3 && inv[a] > 0 && cell == 0 &&
-                           cheb(nr, nc, TSEL(cfg.spawn_pos, team, 0), TSEL(cfg.spawn_pos, team, 1)) > 1 &&
-                           cheb(nr, nc, TSEL(cfg.spawn_pos, 1 - team, 0), TSEL(cfg.spawn_pos, 1 - team, 1)) > 1) {
-                    if (s.lead) {
-                        s.sg[nr * G + nc] = 2;  // add_block (:614-634)
-                        inv[a] -= 1;
-                    }
-                    if (METRICS) {
-                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID, a, 1);
-                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OWN_FLAG, a,
-                                            cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)));
-                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_LAID_DIST_OPP_FLAG, a,
-                                            cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)));
-                    }
-                } else if (action < 5 && type == 3 && (cell == 2 || cell == 3)) {
-                    if (cell == 2) {
-                        if (s.lead) s.sg[nr * G + nc] = 3;  // mine_block (:677-690)
-                    } else {
-                        if (s.lead) {
-                            s.sg[nr * G + nc] = 0;
-                            if (inv[a] < 1000) inv[a] += 1;
-                        }
-                        metric_add<METRICS>(cfg, s, CTF_M_BLOCKS_MINED, a, 1);
-                    }
-                }
-            }
-
-            STEP_STAMP(4 + 3 * (k & 7));
-            // ---- tagging_logic (:796-837): sub-lane q evaluates opponent q0+q; hits are applied in opponent order
-            const double dmg = sel4(cfg.type_damage, type);
-            if (!(STEP_ABLATE & 1) && dmg > 0) {
-                double mult = 1.0;
-                if (type == 1 && cheb(pr, pc, TSEL(cfg.flag_pos, team, 0), TSEL(cfg.flag_pos, team, 1)) <= 3) mult = cfg.guard_mult;
-                const double hit = dmg * mult;
-                const int no = cfg_nopp(cfg, team);
-                int q0 = 0;
-#pragma unroll 1
-                while (q0 < no) {
-                    const int left = no - q0;
-                    const int cnt = left < W ? left : W;  // opponents evaluated in this pass
-                    mtw_ensure<W>(np_, j, s.gshift, (uint32_t)(2 * cnt));
-                    bool is_hit = false;
-                    if (j < cnt) {
-                        const int o = cfg_opp(cfg, team, q0 + j);
-                        const uint32_t wa = mt_temper(np_.win[np_.cur + 2 * j]) >> 5, wb = mt_temper(np_.win[np_.cur + 2 * j + 1]) >> 6;
-                        const double u = ((double)wa * 67108864.0 + (double)wb) * (1.0 / 9007199254740992.0);  // np.random.rand()
-                        is_hit = (u < cfg.tag_p) && cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1;
-                    }
-                    const uint32_t hits = s.ballot(is_hit);
-                    if (hits == 0) {  // nobody tagged: all cnt doubles consumed
-                        np_.cur += 2 * cnt;
-                        q0 += cnt;
-                        continue;
-                    }
-                    const int first = __ffs((int)hits) - 1;
-                    np_.cur += 2 * (first + 1);  // doubles up to and including the tagged opponent's
-                    const int o = cfg_opp(cfg, team, q0 + first);
-                    const double h = ld_hp(s, o) - hit;
-                    if (s.lead) st_hp(s, o, h);
-                    metric_add<METRICS>(cfg, s, CTF_M_TAG_COUNT, a, 1);
-                    if (h <= 0) {
-                        if ((flagm >> o) & 1u) metric_add<METRICS>(cfg, s, CTF_M_FLAG_DISPOSSESSIONS, a, 1);
-                        respawn<W>(cfg, s, np_, o, flagm, status);  // may draw randint words right here
-                        resp_mask |= 1u << a;
-                        metric_add<METRICS>(cfg, s, CTF_M_RESPAWN_TAG_COUNT, a, 1);
-                    }
-                    q0 += first + 1;
-                }
-            }
-
-            STEP_STAMP(5 + 3 * (k & 7));
-            // ---- metric-only section (:879-902): one teammate / opponent per sub-lane
-            if (METRICS && !(STEP_ABLATE & 2)) {
-                if (cheb(pr, pc, TSEL(cfg.capture_pos, team, 0), TSEL(cfg.capture_pos, team, 1)) <= 3)
-                    metric_set<METRICS>(cfg, s, CTF_M_STEPS_DEFENDING_ZONE, a, 1);
-                if (cheb(pr, pc, TSEL(cfg.capture_pos, 1 - team, 0), TSEL(cfg.capture_pos, 1 - team, 1)) <= 3)
-                    metric_set<METRICS>(cfg, s, CTF_M_STEPS_ATTACKING_ZONE, a, 1);
-                const int n_own = cfg_nopp(cfg, 1 - team), n_opp = cfg_nopp(cfg, team);
-                int adj_own = 0, adj_opp = 0;
-                for (int q = j; q < 8; q += W) {  // lists hold at most 8 agents
-                    bool near_own = false, near_opp = false;
-                    if (q < n_own) {  // OPPONENTS[1-team]: own team, self included
-                        const int mt = cfg_opp(cfg, 1 - team, q);
-                        near_own = cheb(pr, pc, ps[2 * mt], ps[2 * mt + 1]) <= 1;
-                    }
-                    if (q < n_opp) {
-                        const int o = cfg_opp(cfg, team, q);
-                        near_opp = cheb(pr, pc, ps[2 * o], ps[2 * o + 1]) <= 1;
-                    }
-                    adj_own += __popc(s.ballot(near_own));
-                    adj_opp += __popc(s.ballot(near_opp));
-                    if (q - j + W >= (n_own > n_opp ? n_own : n_opp)) break;  // group-uniform exit
-                }
-                metric_set<METRICS>(cfg, s, CTF_M_STEPS_ADJ_TEAMMATE, a, adj_own);
-                metric_set<METRICS>(cfg, s, CTF_M_STEPS_ADJ_OPPONENT, a, adj_opp);
-            }
-            STEP_STAMP(6 + 3 * (k & 7));
-        }
-    }  // phase
-
-    // heal_agents (:839-847), after its shuffle above; order is irrelevant to the result: one agent per sub-lane
-    for (int a = j; a < N; a += W) {
-        const double mx = sel4(cfg.type_hp, cfg_type(cfg, a));
-        double h = ld_hp(s, a);
-        if (h < mx) {
-            h += cfg.heal;
-            st_hp(s, a, h > mx ? mx : h);
-        }
-    }
-
-    // rewards: act() reward, + tagging reward, adjusted (:957-966), terminal (:920-940) — same op order; one agent per sub-lane
-    const bool terminal = (step == cfg.game_steps);
-    int winner = -1, margin = 0;
-    if (terminal) {
-        margin = iabs_(caps[0] - caps[1]);
-        winner = caps[0] > caps[1] ? 0 : (caps[0] < caps[1] ? 1 : -1);
-    }
-    const int flags_in = misc[3];
-    const int done_now = ((flags_in & CTF_F_DONE) != 0) || terminal;
-    for (int i = j; i < N; i += W) {
-        const int team = cfg_team(cfg, i);
-        double r = 0.0 + cfg.r_step;
-        if ((cap_mask >> i) & 1u) r += cfg.r_capture;
-        r += ((resp_mask >> i) & 1u) ? cfg.r_tag : 0.0;
-        if (cfg.use_adjusted) r -= (((cap_team >> (1 - team)) & 1u) ? 1.0 : 0.0) * cfg.r_capture * cfg.punish;
-        if (winner >= 0) {
-            if (team == winner) r += margin * cfg.win_scalar;
-            else r -= margin * cfg.loss_scalar;
-        }
-        if (rw32) rw32[(size_t)e * N + i] = (float)r;
-        if (rw64) rw64[(size_t)e * N + i] = r;
-        if (METRICS && !(STEP_ABLATE & 16)) {  // update_visitation_map (:479-486) as a log entry: slot step % 512
-            p.vislog[((size_t)(step & (CTF_VIS_LOG - 1)) * cfg.n_envs + e) * N + i] = (uint16_t)(ps[2 * i] * G + ps[2 * i + 1]);
-        }
-    }
-
-    STEP_STAMP(30);
-    // ---- the replicated registers go back to the record (sub-lane 0)
-    if (s.lead) {
-        misc[0] = step;
-        misc[1] = caps[0];
-        misc[2] = caps[1];
-        misc[3] = (vis_flags & ~CTF_F_DONE) | (done_now ? CTF_F_DONE : 0);
-        if (done_out) done_out[e] = (uint8_t)done_now;
-#pragma unroll
-        for (int i = 0; i < CTF_MAX_AGENTS; i++) {
-            if (i < N) {
-                s.sr[cfg.off_flag + i] = (uint8_t)((flagm >> i) & 1u);
-                s.sr[cfg.off_perm + i] = (uint8_t)((perm >> (4 * i)) & 15u);
-            }
-        }
-    }
-}
-
-template <bool METRICS, int W>
-__global__ void __launch_bounds__(WAVE)
-#if STEP_TRACE
-__attribute__((amdgpu_waves_per_eu(4, 4)))  // a trace must keep the shipped kernel's residency (16 blocks per CU)
-#endif
-k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
-                                                float* __restrict__ rw32, double* __restrict__ rw64,
-                                                uint8_t* __restrict__ done_out, uint32_t flags) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restrict__ rw32, double* __restrict__ rw64,
+       uint8_t* __restrict__ done_out, uint32_t flags) {
     constexpr int EPW = WAVE / W;  // envs per wave
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
     STEP_STAMP(0);
@@ -745,33 +188,58 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
     const int nvalid = min(EPW, cfg.n_envs - env0);
     const int SLB = step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     const int SLW = SLB / 4, GW = cfg.GS / 4, RW = cfg.RS / 4;
-    const int AW = 4, WW = 2 * WCAP;  // action words, RNG window words per slot
+    const int AW = 4, WW = PY_RING;  // action words, ring words per slot
     const int N = cfg.N;
     const int e = env0 + g;
-    // the two stream positions: asked for before the staging loads, needed right behind the barrier
+    const bool live = g < nvalid;
+    // the two ring positions: the addresses of the step's random words depend on them, so they go first
     uint32_t rp_py = 0, rp_np = 0;
-    if (g < nvalid) {
+    if (live) {
         rp_py = p.rngpos[2 * e];
         rp_np = p.rngpos[2 * e + 1];
     }
 
-    // ---- stage the wave's envs' grids, records and actions into LDS.  Flat, coalesced 16-byte loads, unrolled so
-    // that every lane has several independent loads in flight (a rolled per-env loop pays one memory latency per env).
+    // ---- stage the wave's envs' grids, records and actions into LDS.  Flat, coalesced 16-byte loads, the first 4 + 2 per lane
+    // issued before anything waits; the random words' loads follow them as soon as the ring positions are there.
+    const u32x4* gsrc = (const u32x4*)(p.grid + (size_t)env0 * cfg.GS);
+    const u32x4* rsrc = (const u32x4*)(p.rec + (size_t)env0 * cfg.RS);
+    const int GQ = GW / 4, RQ = RW / 4;  // 16-byte quads per env (GS and RS are multiples of 16)
+    const int ng = nvalid * GQ, nr = nvalid * RQ;
+    u32x4 gv[4], rv[2];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        if (lane + WAVE * u < ng) gv[u] = gsrc[lane + WAVE * u];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+        if (lane + WAVE * u < nr) rv[u] = rsrc[lane + WAVE * u];
+    GroupRng<W> R;
+    if (live) group_issue_loads<W>(R, cfg, p, e, j, rp_py, rp_np);
     {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4* gsrc = (const u32x4*)(p.grid + (size_t)env0 * cfg.GS);
-        const u32x4* rsrc = (const u32x4*)(p.rec + (size_t)env0 * cfg.RS);
-        const int GQ = GW / 4, RQ = RW / 4;  // 16-byte quads per env (GS and RS are multiples of 16)
-        const int ng = nvalid * GQ, nr = nvalid * RQ;
-#pragma unroll 4
-        for (int q = lane; q < ng; q += WAVE) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = lane + WAVE * u;
+            if (q < ng) {
+                const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
+                uint32_t* slot = lds + el * SLW + w;
+                slot[0] = gv[u].x; slot[1] = gv[u].y; slot[2] = gv[u].z; slot[3] = gv[u].w;
+            }
+        }
+        for (int q = lane + WAVE * 4; q < ng; q += WAVE) {  // G > 16 only
             const u32x4 v = gsrc[q];
             const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
             uint32_t* slot = lds + el * SLW + w;
             slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
         }
-#pragma unroll 2
-        for (int q = lane; q < nr; q += WAVE) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int q = lane + WAVE * u;
+            if (q < nr) {
+                const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
+                uint32_t* slot = lds + el * SLW + GW + w;
+                slot[0] = rv[u].x; slot[1] = rv[u].y; slot[2] = rv[u].z; slot[3] = rv[u].w;
+            }
+        }
+        for (int q = lane + WAVE * 2; q < nr; q += WAVE) {  // N > 8 only
             const u32x4 v = rsrc[q];
             const int el = (int)fdiv((uint32_t)q, cfg.div_rq), w = (q - el * RQ) * 4;
             uint32_t* slot = lds + el * SLW + GW + w;
@@ -794,53 +262,14 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
     __syncthreads();
     STEP_STAMP(1);
 
-    if (g < nvalid) {
-        StepCtx<W> s;
-        s.sg = (uint8_t*)(lds + g * SLW);
-        s.sr = s.sg + cfg.GS;
-        uint32_t* wins = (uint32_t*)(s.sr + cfg.RS + 16);
-        s.sm = METRICS ? (uint8_t*)(wins + WW) : nullptr;
-        s.j = j;
-        s.gshift = g * W;
-        s.lead = (j == 0);
-        const int8_t* act = (const int8_t*)(s.sr + cfg.RS);
-        int32_t* misc = (int32_t*)(s.sr + cfg.off_misc);
-
-        MtWin py = mtw_open(p.mt_py + (size_t)e * CTF_MT_N, wins, rp_py);
-        MtWin npg = mtw_open(p.mt_np + (size_t)e * CTF_MT_N, wins + WCAP, rp_np);
-
-        if ((flags & CTF_STEP_AUTO_RESET) && (misc[3] & CTF_F_DONE)) {
-            // reset() of this env inside the step launch (not in the reference: opt-in flag); the group's lanes share the copies
-            const uint32_t* src = (const uint32_t*)p.init_grid;
-            for (int w = j; w < GW; w += W) ((uint32_t*)s.sg)[w] = src[w];
-            if (s.lead) reset_record(cfg, s.sr);
-            if (METRICS) {
-                int32_t* m = p.metrics + (size_t)e * CTF_N_METRICS * N;
-                for (int w = j; w < CTF_N_METRICS * N; w += W) m[w] = 0;
-                // (visitation: reset_record flagged the base maps as zero and emptied the log)
-            }
-        }
-
-        uint32_t status = 0;
-        env_step<METRICS, W>(cfg, p, s, act, py, npg, status, e, rw32, rw64, done_out);
-        mtw_flush<W>(py, j);
-        mtw_flush<W>(npg, j);
-        if (s.lead) {
-            p.rngpos[2 * e] = py.pos | (py.lazy ? CTF_LAZY_BIT : 0u);
-            p.rngpos[2 * e + 1] = npg.pos | (npg.lazy ? CTF_LAZY_BIT : 0u);
-            if (status) atomicOr(p.status, status);
-        }
-        STEP_STAMP(31);
-    }
+    if (live) group_step<METRICS, W>(R, cfg, p, (uint8_t*)(lds + g * SLW), e, j, g * W, rp_py, rp_np, flags, rw32, rw64, done_out);
     __syncthreads();
+    STEP_STAMP(2);
 
     // ---- write the envs back (flat, coalesced 16-byte stores)
     {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         u32x4* gdst = (u32x4*)(p.grid + (size_t)env0 * cfg.GS);
         u32x4* rdst = (u32x4*)(p.rec + (size_t)env0 * cfg.RS);
-        const int GQ = GW / 4, RQ = RW / 4;
-        const int ng = nvalid * GQ, nr = nvalid * RQ;
 #pragma unroll 2
         for (int q = lane; q < ((STEP_ABLATE & 64) ? 0 : ng); q += WAVE) {
             const int el = (int)fdiv((uint32_t)q, cfg.div_gq), w = (q - el * GQ) * 4;
@@ -876,7 +305,10 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions,
             }
         }
     }
-    STEP_STAMP(32);
+    STEP_STAMP(3);
+    // ---- the consumed random words are replaced by their successors; the new ring positions
+    if (live) group_finish<W>(R, cfg, p, e, j);
+    STEP_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1525,58 +957,76 @@ extern "C" __global__ void k_export_counters(DevCfg cfg, DevPtrs p, int32_t* met
 }
 
 // ------------------------------------------------------------------------------------------------
-// bulk hand-over of the twin MT19937 states, stream-ordered (the facade's global-RNG contract; checkpoints)
+// hand-over of the twin MT19937 states, stream-ordered (the facade's global-RNG contract; checkpoints)
 // ------------------------------------------------------------------------------------------------
 // Standard form per env and generator: 624 state words + the position (0..624), as random.getstate()[1] /
-// np.random.get_state()[1:3] give them.  One block per env.
+// np.random.get_state()[1:3] give them.  One block per env: block b handles env e0 + b and record b of the arrays.
+// The conversions to / from the run-ahead ring (ctf_mt.h) are sequential: one thread, on a copy in LDS.
 extern "C" __global__ void __launch_bounds__(256) k_import_rng(DevCfg cfg, DevPtrs p, const uint32_t* __restrict__ py,
-                                                               const uint32_t* __restrict__ np_) {
-    const int e = blockIdx.x;
+                                                               const uint32_t* __restrict__ np_, int e0) {
+    __shared__ uint32_t a[CTF_MT_N];
+    __shared__ uint32_t sh_pos, sh_save;
+    const int e = e0 + (int)blockIdx.x, t = threadIdx.x;
     const uint32_t* src[2] = {py, np_};
     uint32_t* dst[2] = {p.mt_py, p.mt_np};
     for (int k = 0; k < 2; k++) {
-        if (!src[k]) continue;
-        const uint32_t* in = src[k] + (size_t)e * (CTF_MT_N + 1);
-        uint32_t* out = dst[k] + (size_t)e * CTF_MT_N;
-        for (int i = threadIdx.x; i < CTF_MT_N; i += blockDim.x) out[i] = in[i];
-        // lazy flag clear: words [pos, 624) are output as they stand
-        if (threadIdx.x == 0) p.rngpos[2 * e + k] = in[CTF_MT_N] > CTF_MT_N ? CTF_MT_N : in[CTF_MT_N];
+        if (!src[k]) continue;  // uniform
+        const uint32_t* in = src[k] + (size_t)blockIdx.x * (CTF_MT_N + 1);
+        for (int i = t; i < CTF_MT_N; i += blockDim.x) a[i] = in[i];
+        __syncthreads();
+        if (t == 0) {
+            uint32_t sv;
+            sh_pos = mt_std_to_runahead(a, in[CTF_MT_N], &sv);
+            sh_save = sv;
+        }
+        __syncthreads();
+        uint32_t* out = dst[k] + (size_t)e * CTF_MT_STRIDE;
+        for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = a[i];
+        for (int i = t; i < CTF_MT_MIRROR; i += blockDim.x) out[CTF_MT_N + i] = a[i];
+        if (t == 0) {
+            out[CTF_MT_SAVE] = sh_save;
+            p.rngpos[2 * e + k] = sh_pos;
+        }
+        __syncthreads();
     }
 }
-// A lazily regenerated block ([0, pos) new, [pos, 624) old) is finished first: word i needs the OLD a[i], a[i + 1] and
-// a[i + 397] for i < 227, the NEW a[i - 227] beyond — chunks of 227 words, every chunk read completely before it is written.
-extern "C" __global__ void __launch_bounds__(256) k_export_rng(DevCfg cfg, DevPtrs p, uint32_t* __restrict__ py, uint32_t* __restrict__ np_) {
+extern "C" __global__ void __launch_bounds__(256) k_export_rng(DevCfg cfg, DevPtrs p, uint32_t* __restrict__ py, uint32_t* __restrict__ np_, int e0) {
     __shared__ uint32_t a[CTF_MT_N];
-    const int e = blockIdx.x, t = threadIdx.x;
+    __shared__ uint32_t sh_pos;
+    const int e = e0 + (int)blockIdx.x, t = threadIdx.x;
     uint32_t* dst[2] = {py, np_};
     const uint32_t* src[2] = {p.mt_py, p.mt_np};
     for (int k = 0; k < 2; k++) {
         if (!dst[k]) continue;  // uniform
-        const uint32_t packed = p.rngpos[2 * e + k];
-        const int pos = (int)(packed & CTF_POS_MASK);
-        for (int i = t; i < CTF_MT_N; i += blockDim.x) a[i] = src[k][(size_t)e * CTF_MT_N + i];
+        const uint32_t* in = src[k] + (size_t)e * CTF_MT_STRIDE;
+        for (int i = t; i < CTF_MT_N; i += blockDim.x) a[i] = in[i];
         __syncthreads();
-        if (packed & CTF_LAZY_BIT) {
-            for (int c = pos; c < CTF_MT_N; c += 227) {
-                const int i = c + t;
-                const bool on = t < 227 && i < CTF_MT_N;
-                uint32_t v = 0;
-                if (on) {
-                    const uint32_t x0 = a[i], x1 = a[i + 1 == CTF_MT_N ? 0 : i + 1];
-                    const uint32_t m = a[i + 397 >= CTF_MT_N ? i + 397 - CTF_MT_N : i + 397];
-                    const uint32_t y = (x0 & 0x80000000u) | (x1 & 0x7fffffffu);
-                    v = m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                }
-                __syncthreads();
-                if (on) a[i] = v;
-                __syncthreads();
-            }
-        }
-        uint32_t* out = dst[k] + (size_t)e * (CTF_MT_N + 1);
+        if (t == 0) sh_pos = mt_runahead_to_std(a, p.rngpos[2 * e + k], in[CTF_MT_SAVE]);
+        __syncthreads();
+        uint32_t* out = dst[k] + (size_t)blockIdx.x * (CTF_MT_N + 1);
         for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = a[i];
-        if (t == 0) out[CTF_MT_N] = (uint32_t)pos;
+        if (t == 0) out[CTF_MT_N] = sh_pos;
         __syncthreads();
     }
+}
+// counter mode: (words consumed from the `random` stream, ... from the np.random stream) of every env
+extern "C" __global__ void k_get_counters(DevCfg cfg, DevPtrs p, unsigned long long* out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cfg.n_envs) return;
+    out[2 * (size_t)e] = p.rngctr[4 * (size_t)e];
+    out[2 * (size_t)e + 1] = p.rngctr[4 * (size_t)e + 1];
+}
+// ... and the way back (a checkpoint restore): the rings are refilled from the given word indices
+extern "C" __global__ void k_set_counters(DevCfg cfg, DevPtrs p, const unsigned long long* in) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cfg.n_envs) return;
+    unsigned long long* ctr = p.rngctr + 4 * (size_t)e;
+    ctr[0] = in[2 * (size_t)e];
+    ctr[1] = in[2 * (size_t)e + 1];
+    ctr_fill_ring(p.mt_py + (size_t)e * CTF_MT_STRIDE, ctr[2], 0u, ctr[0]);
+    ctr_fill_ring(p.mt_np + (size_t)e * CTF_MT_STRIDE, ctr[3], 1u, ctr[1]);
+    p.rngpos[2 * e] = 0;
+    p.rngpos[2 * e + 1] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1723,12 +1173,22 @@ extern "C" hipError_t ctf_launch_export_counters(const DevCfg& cfg, const DevPtr
     hipLaunchKernelGGL(k_export_counters, dim3(blocks), dim3(256), 0, st, cfg, p, metrics, captures, steps);
     return hipGetLastError();
 }
-extern "C" hipError_t ctf_launch_import_rng(const DevCfg& cfg, const DevPtrs& p, const uint32_t* py, const uint32_t* np_, hipStream_t st) {
-    hipLaunchKernelGGL(k_import_rng, dim3(cfg.n_envs), dim3(256), 0, st, cfg, p, py, np_);
+// envs [e0, e0 + count): record b of the arrays belongs to env e0 + b
+extern "C" hipError_t ctf_launch_import_rng(const DevCfg& cfg, const DevPtrs& p, const uint32_t* py, const uint32_t* np_, int e0, int count,
+                                            hipStream_t st) {
+    hipLaunchKernelGGL(k_import_rng, dim3(count), dim3(256), 0, st, cfg, p, py, np_, e0);
     return hipGetLastError();
 }
-extern "C" hipError_t ctf_launch_export_rng(const DevCfg& cfg, const DevPtrs& p, uint32_t* py, uint32_t* np_, hipStream_t st) {
-    hipLaunchKernelGGL(k_export_rng, dim3(cfg.n_envs), dim3(256), 0, st, cfg, p, py, np_);
+extern "C" hipError_t ctf_launch_export_rng(const DevCfg& cfg, const DevPtrs& p, uint32_t* py, uint32_t* np_, int e0, int count, hipStream_t st) {
+    hipLaunchKernelGGL(k_export_rng, dim3(count), dim3(256), 0, st, cfg, p, py, np_, e0);
+    return hipGetLastError();
+}
+extern "C" hipError_t ctf_launch_get_counters(const DevCfg& cfg, const DevPtrs& p, unsigned long long* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_get_counters, dim3((cfg.n_envs + 63) / 64), dim3(64), 0, st, cfg, p, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t ctf_launch_set_counters(const DevCfg& cfg, const DevPtrs& p, const unsigned long long* in, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_counters, dim3((cfg.n_envs + 63) / 64), dim3(64), 0, st, cfg, p, in);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg& cfg, int8_t* actions, uint64_t seed, uint32_t step,

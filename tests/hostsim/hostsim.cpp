@@ -1,0 +1,197 @@
+// hostsim.cpp — the step kernel's LOGIC (marl-ctf-development_amd/csrc/ctf_step_core.h: env_step, the run-ahead MT19937 streams,
+// their hit bits / ring / production) compiled for the host with one lane per env (W = 1), driven from Python through ctypes
+// and compared with the oracle in tests/test_hostsim.py.
+//
+// TEST INFRASTRUCTURE ONLY: a unit test of device code that cannot run in the GPU-less build container.  It is not a CPU path
+// of the product (nothing in marl-ctf-development_amd/ builds, loads or calls it) and it is not the oracle (it is the thing
+// being checked).  Cross-lane behaviour (W > 1: ballots, the slot -> lane rotation) is only covered on the GPU.
+//
+// Build flags let a test shrink the windows so that the rare paths run all the time: -DNP_CH_MAX=1 -DNP_SLACK=0 (the hit-bit
+// window covers almost nothing: direct loads), -DPY_RING=4 -DPY_EXT=2 (the shuffle ring reloads constantly), -DPROD_TQ=1
+// (production in many batches).
+#define CTF_HOSTSIM 1
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+#include <vector>
+
+#include "ctf_step_core.h"
+
+static char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#include "ctf_derive.h"
+
+struct hs_env {
+    DevCfg d;
+    DevPtrs p;
+    std::vector<uint8_t> grid, rec, init_grid;
+    std::vector<uint32_t> mt_py, mt_np, rngpos, vis, status;
+    std::vector<unsigned long long> rngctr;
+    std::vector<int32_t> metrics;
+    std::vector<uint16_t> vislog;
+    std::vector<uint32_t> lds;
+};
+
+// k_step<METRICS, 1> for every env: staging, group_step, write-back, group_finish
+template <bool METRICS>
+static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags) {
+    const DevCfg& d = h->d;
+    const int GW = d.GS / 4, RW = d.RS / 4, AW = 4, WW = PY_RING, N = d.N;
+    uint32_t* lds = h->lds.data();
+    for (int e = 0; e < d.n_envs; e++) {
+        const uint32_t rp_py = h->p.rngpos[2 * e], rp_np = h->p.rngpos[2 * e + 1];
+        GroupRng<1> R;
+        group_issue_loads<1>(R, d, h->p, e, 0, rp_py, rp_np);
+        memcpy(lds, h->grid.data() + (size_t)e * d.GS, (size_t)d.GS);
+        memcpy(lds + GW, h->rec.data() + (size_t)e * d.RS, (size_t)d.RS);
+        memset(lds + GW + RW, 0, 16);
+        memcpy(lds + GW + RW, actions + (size_t)e * N, (size_t)N);
+        if (METRICS) memset(lds + GW + RW + AW + WW, 0, (size_t)((CTF_N_METRICS * N + 3) & ~3));
+        group_step<METRICS, 1>(R, d, h->p, (uint8_t*)lds, e, 0, 0, rp_py, rp_np, flags, rw32, rw64, done);
+        memcpy(h->grid.data() + (size_t)e * d.GS, lds, (size_t)d.GS);
+        memcpy(h->rec.data() + (size_t)e * d.RS, lds + GW, (size_t)d.RS);
+        if (METRICS) {
+            const uint8_t* dl = (const uint8_t*)(lds + GW + RW + AW + WW);
+            for (int w = 0; w < CTF_N_METRICS * N; w++) h->metrics[(size_t)e * CTF_N_METRICS * N + w] += dl[w];
+        }
+        group_finish<1>(R, d, h->p, e, 0);
+    }
+}
+extern "C" {
+
+const char* hs_last_error(void) { return g_err; }
+
+hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
+    hs_env* h = new (std::nothrow) hs_env();
+    if (!h) return nullptr;
+    if (derive(cfg, n_envs, &h->d)) { delete h; return nullptr; }
+    const DevCfg& d = h->d;
+    const size_t E = (size_t)n_envs;
+    h->grid.assign(E * d.GS, 0);
+    h->rec.assign(E * d.RS, 0);
+    h->init_grid.assign((size_t)d.GS, 0);
+    memcpy(h->init_grid.data(), cfg->init_grid, (size_t)d.GG);
+    h->mt_py.assign(E * CTF_MT_STRIDE, 0);
+    h->mt_np.assign(E * CTF_MT_STRIDE, 0);
+    h->rngpos.assign(E * 2, 0);
+    h->rngctr.assign(E * 4, 0);
+    h->metrics.assign(E * CTF_N_METRICS * d.N, 0);
+    h->vis.assign(E * d.N * d.GS, 0);
+    h->vislog.assign((size_t)CTF_VIS_LOG * E * d.N, 0);
+    h->status.assign(1, 0);
+    h->lds.assign((size_t)step_slot_bytes(d.GS, d.RS, d.N, true) / 4 + 4, 0);
+    h->p.grid = h->grid.data(); h->p.rec = h->rec.data();
+    h->p.mt_py = h->mt_py.data(); h->p.mt_np = h->mt_np.data();
+    h->p.rngpos = h->rngpos.data(); h->p.rngctr = h->rngctr.data();
+    h->p.metrics = h->metrics.data(); h->p.vis = h->vis.data(); h->p.vislog = h->vislog.data();
+    h->p.init_grid = h->init_grid.data(); h->p.meta_lut = nullptr; h->p.status = h->status.data();
+    for (size_t e = 0; e < E; e++) {  // k_reset with init_perm
+        memcpy(h->grid.data() + e * d.GS, h->init_grid.data(), (size_t)d.GS);
+        uint8_t* sr = h->rec.data() + e * d.RS;
+        reset_record(d, sr);
+        for (int i = 0; i < d.N; i++) sr[d.off_perm + i] = (uint8_t)i;
+    }
+    return h;
+}
+void hs_destroy(hs_env* h) { delete h; }
+
+static void finish_layout(uint32_t* a, uint32_t save0) {
+    for (int i = 0; i < CTF_MT_MIRROR; i++) a[CTF_MT_N + i] = a[i];
+    a[CTF_MT_SAVE] = save0;
+}
+// standard form (624 words + position) in: what k_import_rng does
+void hs_set_rng_state(hs_env* h, int32_t e, const uint32_t* py, const uint32_t* np_) {
+    const uint32_t* src[2] = {py, np_};
+    uint32_t* dst[2] = {h->p.mt_py, h->p.mt_np};
+    for (int k = 0; k < 2; k++) {
+        if (!src[k]) continue;
+        uint32_t* a = dst[k] + (size_t)e * CTF_MT_STRIDE;
+        memcpy(a, src[k], CTF_MT_N * 4);
+        uint32_t sv;
+        h->p.rngpos[2 * e + k] = mt_std_to_runahead(a, src[k][CTF_MT_N], &sv);
+        finish_layout(a, sv);
+    }
+}
+// ... and out: what k_export_rng does
+void hs_get_rng_state(hs_env* h, int32_t e, uint32_t* py, uint32_t* np_) {
+    uint32_t* dst[2] = {py, np_};
+    const uint32_t* src[2] = {h->p.mt_py, h->p.mt_np};
+    for (int k = 0; k < 2; k++) {
+        if (!dst[k]) continue;
+        const uint32_t* a = src[k] + (size_t)e * CTF_MT_STRIDE;
+        memcpy(dst[k], a, CTF_MT_N * 4);
+        dst[k][CTF_MT_N] = mt_runahead_to_std(dst[k], h->p.rngpos[2 * e + k], a[CTF_MT_SAVE]);
+    }
+}
+// the mirror must equal the ring's first words at every kernel boundary: returns the number of violations
+int32_t hs_check_mirror(hs_env* h) {
+    int32_t bad = 0;
+    for (int e = 0; e < h->d.n_envs; e++)
+        for (int k = 0; k < 2; k++) {
+            const uint32_t* a = (k ? h->p.mt_np : h->p.mt_py) + (size_t)e * CTF_MT_STRIDE;
+            for (int i = 0; i < CTF_MT_MIRROR; i++) bad += a[CTF_MT_N + i] != a[i];
+        }
+    return bad;
+}
+// counter mode: what k_seed does there
+void hs_seed_counter(hs_env* h, int32_t e, uint64_t py_seed, uint64_t np_seed) {
+    const uint64_t seeds[2] = {py_seed, np_seed};
+    for (int k = 0; k < 2; k++) {
+        uint32_t* a = (k ? h->p.mt_np : h->p.mt_py) + (size_t)e * CTF_MT_STRIDE;
+        for (unsigned long long blk = 0; blk < CTF_MT_N / 4; blk++) ctr_block(seeds[k], blk, (uint32_t)k, a + 4 * blk);
+        finish_layout(a, 0u);
+        h->p.rngpos[2 * e + k] = 0;
+        h->p.rngctr[4 * e + k] = 0;
+        h->p.rngctr[4 * e + 2 + k] = seeds[k];
+    }
+}
+void hs_get_counters(hs_env* h, int32_t e, uint64_t* out) { out[0] = h->p.rngctr[4 * e]; out[1] = h->p.rngctr[4 * e + 1]; }
+
+void hs_reset(hs_env* h, int32_t e) {  // k_reset
+    const DevCfg& d = h->d;
+    memcpy(h->grid.data() + (size_t)e * d.GS, h->init_grid.data(), (size_t)d.GS);
+    reset_record(d, h->rec.data() + (size_t)e * d.RS);
+    for (int w = 0; w < CTF_N_METRICS * d.N; w++) h->metrics[(size_t)e * CTF_N_METRICS * d.N + w] = 0;
+}
+
+uint32_t hs_step(hs_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags) {
+    h->status[0] = 0;
+    if (h->d.log_metrics) step_all<true>(h, actions, rw32, rw64, done, flags);
+    else step_all<false>(h, actions, rw32, rw64, done, flags);
+    return h->status[0];
+}
+
+// ctf_get_state without the visitation maps (their log / fold logic is not part of what this harness checks)
+void hs_get_state(hs_env* h, int32_t e, ctf_state_view* out) {
+    const DevCfg& d = h->d;
+    memset(out, 0, sizeof(*out));
+    memcpy(out->grid, h->grid.data() + (size_t)e * d.GS, (size_t)d.GG);
+    const uint8_t* rec = h->rec.data() + (size_t)e * d.RS;
+    for (int i = 0; i < d.N; i++) {
+        memcpy(&out->hp[i], rec + 8 * i, 8);
+        out->pos[i][0] = (int8_t)rec[d.off_pos + 2 * i];
+        out->pos[i][1] = (int8_t)rec[d.off_pos + 2 * i + 1];
+        out->has_flag[i] = rec[d.off_flag + i];
+        out->perm[i] = rec[d.off_perm + i];
+        int16_t inv;
+        memcpy(&inv, rec + d.off_inv + 2 * i, 2);
+        out->inventory[i] = inv;
+    }
+    int32_t misc[4];
+    memcpy(misc, rec + d.off_misc, 16);
+    out->step_count = misc[0];
+    out->team_captures[0] = misc[1];
+    out->team_captures[1] = misc[2];
+    out->done = (misc[3] & CTF_F_DONE) ? 1 : 0;
+    if (d.log_metrics)
+        for (int k = 0; k < CTF_N_METRICS; k++)
+            for (int i = 0; i < d.N; i++) out->metrics[k][i] = h->metrics[((size_t)e * CTF_N_METRICS + k) * d.N + i];
+}
+
+}  // extern "C"

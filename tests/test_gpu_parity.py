@@ -160,6 +160,50 @@ def test_batch_matches_oracle(name, n_envs, steps, log_metrics, tiles, monkeypat
     vec.close()
 
 
+@pytest.mark.parametrize("name", ["arena_stress", "split_random", "syn_edge_k1"])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+def test_every_step_lane_width_matches_the_oracle(name, lanes, monkeypatch):
+    """k_step gives every env a group of W lanes (W = the power of two covering the larger opponents list); CTF_STEP_W forces
+    another width, with more tagging passes per turn (W < opponents) or idle lanes (W > opponents).  The slot -> lane rotation of
+    the hit bits, the randint nibbles fetched from their owner lane and the split of the production all depend on W: every width
+    must give the oracle's trajectory, MT19937 states included."""
+    monkeypatch.setenv("CTF_STEP_W", str(lanes))
+    case = Case(name)
+    n_envs, steps = 150, 140
+    seeds = np.arange(n_envs, dtype=np.uint64) * 131 + 3
+    vec = pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=seeds, **case.kwargs)
+    cfg, _ = case.config()
+    refs = [oracle.OracleEnv(cfg) for _ in range(n_envs)]
+    for e, r in enumerate(refs):
+        r.seed(int(seeds[e]), int(seeds[e]))
+    acts = torch.empty((n_envs, case.n), dtype=torch.int8, device=vec.device)
+    alive = np.ones(n_envs, bool)
+    for t in range(steps):
+        vec.random_actions(acts, seed=0xBEEF, step=t, env_offset=5)
+        vec.step(acts, auto_reset=True, want_f64=True)
+        a, r64, d = acts.cpu().numpy(), vec.rewards64.cpu().numpy(), vec.done.cpu().numpy()
+        for e, r in enumerate(refs):
+            if not alive[e]:
+                continue
+            if r.get_state().done:
+                r.reset()
+            rw, dn, status = r.step(a[e])
+            if status:
+                alive[e] = False
+                continue
+            assert np.array_equal(r64[e], rw) and int(d[e]) == int(dn), f"{name} W={lanes} env {e} step {t}"
+        if t % 20 == 19:
+            for e in range(0, n_envs, 7):
+                if alive[e]:
+                    _state_equal(view_arrays(vec.get_state(e), case.n, case.g), view_arrays(refs[e].get_state(), case.n, case.g),
+                                 f"{name} W={lanes} env {e} step {t}")
+                    py, npw = vec.get_rng_state(e)
+                    rpy, rnp = refs[e].get_rng_state()
+                    assert np.array_equal(py, rpy) and np.array_equal(npw, rnp), f"{name} W={lanes} env {e} step {t}: MT19937 states"
+    assert alive.sum() >= (n_envs // 8 if name == "syn_edge_k1" else n_envs // 2)
+    vec.close()
+
+
 def test_full_size_arena_properties_and_sample():
     """BASELINE configs[2] size (65 536 arena envs): size-independent properties on everything plus a
     bit-exact oracle check on a 64-env sample."""
