@@ -46,6 +46,8 @@ extern "C" {
 #define CTF_ST_BAD_ACTION 1u   /* action outside 0..8: reference raises KeyError (gridworld_ctf.py:710) */
 #define CTF_ST_NO_RESPAWN 2u   /* no open cell round the spawn: np.random.randint(0) ValueError (:771)  */
 #define CTF_ST_SPAWN_EDGE 4u   /* respawn offset went negative (spawn on row/col 0, the WARNING at :773) */
+#define CTF_ST_RNG_OVERRUN 8u  /* one step drew more than ~624 words from one generator: its rejection loops cannot be
+                                  followed further (a run of > 500 rejected draws: does not happen)                  */
 
 /* ctf_config.rng_mode */
 #define CTF_RNG_MT19937 0 /* the reference's two MT19937 generators, bit for bit (default)                          */

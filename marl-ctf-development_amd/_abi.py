@@ -18,6 +18,7 @@ MT_N = 624
 ST_BAD_ACTION = 1
 ST_NO_RESPAWN = 2
 ST_SPAWN_EDGE = 4
+ST_RNG_OVERRUN = 8
 STEP_AUTO_RESET = 1
 RNG_MT19937 = 0
 RNG_COUNTER = 1

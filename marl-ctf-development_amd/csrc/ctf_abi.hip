@@ -22,6 +22,7 @@ extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, ui
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t ctf_launch_import_rng(const DevCfg&, const DevPtrs&, const uint32_t*, const uint32_t*, int, int, hipStream_t);
 extern "C" hipError_t ctf_launch_export_rng(const DevCfg&, const DevPtrs&, uint32_t*, uint32_t*, int, int, hipStream_t);
+extern "C" hipError_t ctf_launch_rng_refill(const DevCfg&, const DevPtrs&, int, int, int, hipStream_t);
 extern "C" hipError_t ctf_launch_get_counters(const DevCfg&, const DevPtrs&, unsigned long long*, hipStream_t);
 extern "C" hipError_t ctf_launch_set_counters(const DevCfg&, const DevPtrs&, const unsigned long long*, hipStream_t);
 extern "C" hipError_t ctf_launch_export_counters(const DevCfg&, const DevPtrs&, int32_t*, int32_t*, int32_t*, hipStream_t);
@@ -34,7 +35,20 @@ struct ctf_env {
     int n_cus;
     uint64_t* seed_scratch;  // device, 2*E u64
     uint32_t* rng_scratch;   // device, 2 x 625 u32: one env's two generators in the standard form (ctf_set/get_rng_state)
+    int steps_since_refill;  // step launches since the bulk ring refill last ran (ctf_mt.h; cadence d.rng_refill_every)
 };
+
+// Every step launch goes through here first: the rings the consumers have left are regenerated every rng_refill_every steps, which
+// is always before any of them is needed again (ctf_derive.h; the step kernel has its own safety net all the same).
+static hipError_t before_step(ctf_env* h, hipStream_t st) {
+    hipError_t rc = hipSuccess;
+    if (h->d.rng_refill_every > 0 && h->steps_since_refill >= h->d.rng_refill_every) {
+        rc = ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 0, st);
+        h->steps_since_refill = 0;
+    }
+    h->steps_since_refill++;
+    return rc;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -74,6 +88,7 @@ static void free_all(ctf_env* h) {
     (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis); (void)hipFree(h->p.vislog);
     (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
     (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch);
+    (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib);
     delete h;
 }
 
@@ -93,6 +108,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     memset(&h->p, 0, sizeof(h->p));
     h->seed_scratch = nullptr;
     h->rng_scratch = nullptr;
+    h->steps_since_refill = 0;
     h->cfg = *cfg; h->d = d; h->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
@@ -103,8 +119,11 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { free_all(h); return fail(CTF_E_NOMEM, "hipMalloc(%zu) failed", (size_t)(bytes)); }
     ALLOC(h->p.grid, E * d.GS);
     ALLOC(h->p.rec, E * d.RS);
-    ALLOC(h->p.mt_py, E * CTF_MT_STRIDE * 4);
-    ALLOC(h->p.mt_np, E * CTF_MT_STRIDE * 4);
+    ALLOC(h->p.mt_py, E * 2 * CTF_MT_N * 4);
+    ALLOC(h->p.mt_np, E * 2 * CTF_MT_N * 4);
+    ALLOC(h->p.py_top, E * 2 * CTF_P8_DW * 4);
+    ALLOC(h->p.np_hit, E * 2 * CTF_HB_DW * 4);
+    ALLOC(h->p.np_nib, E * 2 * CTF_NB_DW * 4);
     ALLOC(h->p.rngpos, E * 2 * 4);
     ALLOC(h->p.rngctr, (d.rng_mode == CTF_RNG_COUNTER ? E * 4 : 1) * 8);
     ALLOC(h->rng_scratch, 2 * (CTF_MT_N + 1) * 4);
@@ -129,6 +148,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     hipError_t e4 = ctf_launch_reset(h->d, h->p, nullptr, 1, nullptr);
     hipError_t e5 = hipMemset(h->seed_scratch, 0, E * 2 * 8);
     hipError_t e6 = ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, nullptr);
+    if (e6 == hipSuccess) e6 = ctf_launch_rng_refill(h->d, h->p, 0, n_envs, 1, nullptr);
     hipError_t e7 = hipDeviceSynchronize();
     if (e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
         const hipError_t bad = e4 != hipSuccess ? e4 : e5 != hipSuccess ? e5 : e6 != hipSuccess ? e6 : e7;
@@ -165,6 +185,8 @@ extern "C" int ctf_seed(ctf_env* h, const uint64_t* py_seeds, const uint64_t* np
     HIP_TRY(hipMemcpyAsync(h->seed_scratch, py_seeds, E * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(h->seed_scratch + E, np_seeds, E * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, st));
+    HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, st));  // the blocks after the seeded ones, and all digests
+    h->steps_since_refill = 0;
     HIP_TRY(hipStreamSynchronize(st));  // the host arrays are the caller's; do not outlive the call
     return CTF_OK;
 }
@@ -193,6 +215,7 @@ extern "C" int ctf_set_rng_state(ctf_env* h, int32_t e, const uint32_t* py, cons
         // the two records are not adjacent when only one is given: one launch per generator
         if (dev[0]) HIP_TRY(ctf_launch_import_rng(h->d, h->p, dev[0], nullptr, e, 1, nullptr));
         if (dev[1]) HIP_TRY(ctf_launch_import_rng(h->d, h->p, nullptr, dev[1], e, 1, nullptr));
+        HIP_TRY(ctf_launch_rng_refill(h->d, h->p, e, 1, 1, nullptr));  // (a stream that was not handed over is simply redone)
         HIP_TRY(hipDeviceSynchronize());
     }
     return CTF_OK;
@@ -220,6 +243,8 @@ extern "C" int ctf_set_rng_states(ctf_env* h, const uint32_t* py_dev, const uint
     if (int rc = need_mode(h, CTF_RNG_MT19937, "ctf_set_rng_states")) return rc;
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_import_rng(h->d, h->p, py_dev, np_dev, 0, h->d.n_envs, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, (hipStream_t)stream));
+    h->steps_since_refill = 0;
     return CTF_OK;
 }
 
@@ -245,6 +270,8 @@ extern "C" int ctf_set_rng_counters(ctf_env* h, const uint64_t* counters_dev, vo
     if (int rc = need_mode(h, CTF_RNG_COUNTER, "ctf_set_rng_counters")) return rc;
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_set_counters(h->d, h->p, (const unsigned long long*)counters_dev, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, (hipStream_t)stream));
+    h->steps_since_refill = 0;
     return CTF_OK;
 }
 
@@ -258,6 +285,7 @@ extern "C" int ctf_reset(ctf_env* h, const uint8_t* mask_dev, void* stream) {
 extern "C" int ctf_step(ctf_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
+    HIP_TRY(before_step(h, (hipStream_t)stream));
     HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, (hipStream_t)stream));
     return CTF_OK;
 }
@@ -286,6 +314,7 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
                                 uint16_t* meta, uint32_t reverse_mask, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
+    HIP_TRY(before_step(h, (hipStream_t)stream));
     HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, (hipStream_t)stream));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));

@@ -7,11 +7,13 @@
 //   rec    u8  [E][RS]        one record per env, RS multiple of 16:
 //                               f64 hp[N] | i8 pos[N][2] | u8 has_flag[N] | u8 perm[N] | i16 inv[N]
 //                               | i32 step | i32 caps[2] | i32 flags (done, visitation log state)
-//   mt_py  u32 [E][CTF_MT_STRIDE]  CPython `random` stream: MT19937 in RUN-AHEAD form (ctf_mt.h) — the ring of the next 624
-//                                  raw outputs + a mirror of its first words + the saved old word 0
-//   mt_np  u32 [E][CTF_MT_STRIDE]  NumPy legacy `np.random` stream, same form
-//   rngpos u32 [E][2]         per stream: ring position (0..623) of the next output
-//   rngctr u64 [E][2]         counter mode only (cfg.rng_mode == 1): words consumed so far from each stream
+//   mt_py  u32 [E][2][624]    CPython `random` stream: two rings of raw MT19937 words, the current block and the next (ctf_mt.h)
+//   mt_np  u32 [E][2][624]    NumPy legacy `np.random` stream, same form
+//   py_top u32 [E][2][176]    digest of a `random` ring: the top byte of every tempered word + mirror of the other ring's head
+//   np_hit u32 [E][2][26]     digests of an np.random ring: per position, is the rand() that starts there < TAG_PROBABILITY ...
+//   np_nib u32 [E][2][92]     ... and the low 4 bits of the tempered word (randint over the spawn window); + mirrors
+//   rngpos u32 [E][2]         per stream: position 0..624 in the current ring | current ring << 16 | other ring ready << 17
+//   rngctr u64 [E][4]         counter mode only (cfg.rng_mode == 1): stream index of word 0 of the current ring (py, np), seeds (py, np)
 //   metric i32 [E][13][N]     agent-level counters (only when log_metrics)
 //   vislog u16 [512][E][N]    visitation LOG: entry (step % 512) = the cell of every agent after that step; the
 //                             maps are rebuilt from it on export, so a step writes 2N coalesced bytes per env
@@ -46,6 +48,8 @@ struct DevCfg {
     FastDiv div_cgg, div_gg, div_g, div_m, div_n, div_gq, div_rq, div_mn, div_mw;
     FastDiv div_gg_row;             // / GG over 0 .. N*GG (the compact observation's rows)
     int32_t step_lanes_override;    // 0 = automatic; set from CTF_STEP_W for profiling
+    int32_t rng_refill_every;       // steps between two launches of the bulk ring refill (derived: a ring is never needed before)
+    int32_t step_stagger;           // start offset between the four cohorts of k_step's blocks, in 10 ns ticks (0 = none)
     // np.random.rand() < TAG_PROBABILITY on the 53-bit integer x = (a >> 5) * 2^26 + (b >> 6): x < tag_thr, split at bit 26
     uint32_t tag_th, tag_tl;
     int32_t np_pairs;               // rand() draws of one step without respawns: sum over the agents that deal damage of their opponents
@@ -81,7 +85,10 @@ struct DevPtrs {
     uint32_t* mt_py;
     uint32_t* mt_np;
     uint32_t* rngpos;
-    unsigned long long* rngctr;  // counter mode: u64 [E][4] = words consumed (py, np), stream seeds (py, np)
+    unsigned long long* rngctr;  // counter mode: u64 [E][4] = stream index of the current ring's word 0 (py, np), stream seeds (py, np)
+    uint32_t* py_top;
+    uint32_t* np_hit;
+    uint32_t* np_nib;
     int32_t* metrics;
     uint32_t* vis;             // base maps u32 [E][N][GS]; valid only when the env's CTF_F_BASE_ZERO flag is clear
     uint16_t* vislog;          // u16 [CTF_VIS_LOG][E][N]

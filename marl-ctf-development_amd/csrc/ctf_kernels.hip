@@ -12,6 +12,19 @@
 #include <cstdlib>
 
 #include "ctf_device.h"
+// Profiling-only phase trace of the step kernel (tools/trace_step.py): lane 0 of every block stamps the 100 MHz wall clock at
+// fixed points (0 start, 1 staged, 7 hit bits, 5 ring, 6 shuffle 1, 8/9/10 + 3 k act / tagging / metrics of turn k, 32 turns
+// done, 33 shuffle 2, 34 stepped, 2 barrier, 3 written back, 4 end); never defined in the shipped build.
+#ifndef STEP_TRACE
+#define STEP_TRACE 0
+#endif
+#if STEP_TRACE
+__device__ unsigned long long g_step_trace[8192][40];
+#ifndef STEP_TRACE_MASK
+#define STEP_TRACE_MASK 0xFFFFFFFFFFull
+#endif
+#define CTF_STAMP(k) do { if (((STEP_TRACE_MASK >> (k)) & 1ull) && threadIdx.x == 0 && blockIdx.x < 8192) g_step_trace[blockIdx.x][(k)] = wall_clock64(); } while (0)
+#endif
 #include "ctf_step_core.h"
 
 #define WAVE 64
@@ -74,50 +87,31 @@ __device__ void mt_init_by_array(uint32_t* mt, const uint32_t* key, int len) {
     mt[0] = 0x80000000u;
 }
 
-// the mirror of the ring's first words and the saved old word 0 (ctf_mt.h)
-__device__ void mt_finish_layout(uint32_t* a, uint32_t save0) {
-    for (int i = 0; i < CTF_MT_MIRROR; i++) a[CTF_MT_N + i] = a[i];
-    a[CTF_MT_SAVE] = save0;
-}
-// the ring of a counter-mode stream whose next word is word n: ring position 0 holds word n
-__device__ void ctr_fill_ring(uint32_t* a, unsigned long long seed, uint32_t stream, unsigned long long n) {
-    for (unsigned long long blk = n >> 2; (blk << 2) < n + CTF_MT_N; blk++) {
-        uint32_t o[4];
-        ctr_block(seed, blk, stream, o);
-        for (int k = 0; k < 4; k++) {
-            const unsigned long long w = (blk << 2) + (unsigned long long)k;
-            if (w >= n && w < n + CTF_MT_N) a[(uint32_t)(w - n)] = o[k];
-        }
-    }
-    mt_finish_layout(a, 0u);
-}
-
-// py_seeds / np_seeds: device arrays [E].  After this, env e == random.seed(py) ; np.random.seed(np) (MT19937 mode), or its
-// two streams are the counter streams of these seeds from word 0 (counter mode).
+// py_seeds / np_seeds: device arrays [E].  After this (and the k_rng_refill(init) launch that follows it), env e ==
+// random.seed(py) ; np.random.seed(np) (MT19937 mode: ring 0 = the seeded state, position 624, as CPython / NumPy hold it), or
+// its two streams are the counter streams of these seeds at word 0 (counter mode).
 extern "C" __global__ void k_seed(DevCfg cfg, DevPtrs p, const uint64_t* py_seeds, const uint64_t* np_seeds) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.n_envs) return;
-    uint32_t* a_py = p.mt_py + (size_t)e * CTF_MT_STRIDE;
-    uint32_t* a_np = p.mt_np + (size_t)e * CTF_MT_STRIDE;
+    uint32_t* a_py = p.mt_py + (size_t)e * 2 * CTF_MT_N;
+    uint32_t* a_np = p.mt_np + (size_t)e * 2 * CTF_MT_N;
     const uint64_t ps = py_seeds[e], ns = np_seeds[e];
     if (cfg.rng_mode == CTF_RNG_COUNTER) {
-        ctr_fill_ring(a_py, ps, 0u, 0ull);
-        ctr_fill_ring(a_np, ns, 1u, 0ull);
+        for (unsigned long long blk = 0; blk < CTF_MT_N / 4; blk++) {
+            ctr_block(ps, blk, 0u, a_py + 4 * blk);
+            ctr_block(ns, blk, 1u, a_np + 4 * blk);
+        }
         unsigned long long* ctr = p.rngctr + 4 * (size_t)e;
         ctr[0] = 0; ctr[1] = 0; ctr[2] = ps; ctr[3] = ns;
+        p.rngpos[2 * e + 0] = CTF_RP_MAKE(0, 0, 0);
+        p.rngpos[2 * e + 1] = CTF_RP_MAKE(0, 0, 0);
     } else {
         uint32_t key[2] = {(uint32_t)ps, (uint32_t)(ps >> 32)};
         mt_init_by_array(a_py, key, key[1] ? 2 : 1);
         mt_init_genrand(a_np, (uint32_t)ns);
-        // both generators start exhausted (position 624): the run-ahead ring is the whole first regenerated block
-        uint32_t sv;
-        mt_std_to_runahead(a_py, CTF_MT_N, &sv);
-        mt_finish_layout(a_py, sv);
-        mt_std_to_runahead(a_np, CTF_MT_N, &sv);
-        mt_finish_layout(a_np, sv);
+        p.rngpos[2 * e + 0] = CTF_RP_MAKE(CTF_MT_N, 0, 0);  // both generators start exhausted: the first draw comes from the next block
+        p.rngpos[2 * e + 1] = CTF_RP_MAKE(CTF_MT_N, 0, 0);
     }
-    p.rngpos[2 * e + 0] = 0;
-    p.rngpos[2 * e + 1] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -158,20 +152,17 @@ extern "C" __global__ void __launch_bounds__(WAVE) k_reset(DevCfg cfg, DevPtrs p
 // 64 / W envs per wave means W times more waves (4 per SIMD for the arena) to hide the latency chain.
 // The logic itself — env_step, the two streams, group_step / group_finish — is ctf_step_core.h.
 //
-// Profiling-only phase trace (tools/trace_step.py): lane 0 of every block stamps the 100 MHz wall clock at fixed points
-// (0 start, 1 staged, 2 stepped, 3 written back, 4 end); never defined in the shipped build.
-#ifndef STEP_TRACE
-#define STEP_TRACE 0
-#endif
 #if STEP_TRACE
-__device__ unsigned long long g_step_trace[8192][8];
-#define STEP_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_step_trace[blockIdx.x][(k)] = wall_clock64(); } while (0)
+#define STEP_STAMP(k) CTF_STAMP(k)
 extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_trace), sizeof(g_step_trace));
 }
 #else
 #define STEP_STAMP(k) do { } while (0)
 #endif
+
+#define STEP_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
+        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // 16 blocks (= waves) per CU fit by LDS: the register budget is held to the matching 4 waves per SIMD (128 VGPRs)
 template <bool METRICS, int W>
@@ -183,16 +174,29 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
     STEP_STAMP(0);
+#if STEP_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192)
+        g_step_trace[blockIdx.x][39] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                       ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+#endif
+    // Every block of the launch is resident at once, so without this all waves would load, compute and store in step: the
+    // memory system idles while they compute and is swamped at both ends.  The four quarters of the grid start a quarter of
+    // `step_stagger` apart instead (sleeping costs no issue slots): one cohort's loads / stores run under the others' turns.
+    if (cfg.step_stagger) {
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long wait = (unsigned long long)((4u * blockIdx.x) / gridDim.x) * (unsigned long long)cfg.step_stagger;
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     const int g = lane / W, j = lane % W;
     const int env0 = blockIdx.x * EPW;
     const int nvalid = min(EPW, cfg.n_envs - env0);
     const int SLB = step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     const int SLW = SLB / 4, GW = cfg.GS / 4, RW = cfg.RS / 4;
-    const int AW = 4, WW = PY_RING;  // action words, ring words per slot
+    const int AW = 4, WW = STEP_RNG_WORDS;  // action words, digest-window words per slot
     const int N = cfg.N;
     const int e = env0 + g;
     const bool live = g < nvalid;
-    // the two ring positions: the addresses of the step's random words depend on them, so they go first
+    // the two stream positions: the addresses of the step's random digests depend on them, so they go first
     uint32_t rp_py = 0, rp_np = 0;
     if (live) {
         rp_py = p.rngpos[2 * e];
@@ -259,11 +263,13 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
             }
         }
     }
-    __syncthreads();
+    // a block is ONE wave: LDS operations of a wave complete in order, so the staged bytes only need the wave's own LDS
+    // counter — a __syncthreads() would also drain every outstanding global load (the random words') and store
+    STEP_LDS_SYNC();
     STEP_STAMP(1);
 
-    if (live) group_step<METRICS, W>(R, cfg, p, (uint8_t*)(lds + g * SLW), e, j, g * W, rp_py, rp_np, flags, rw32, rw64, done_out);
-    __syncthreads();
+    if (live) group_step<METRICS, W>(R, cfg, p, (uint8_t*)(lds + g * SLW), e, j, g * W, flags, rw32, rw64, done_out);
+    STEP_LDS_SYNC();
     STEP_STAMP(2);
 
     // ---- write the envs back (flat, coalesced 16-byte stores)
@@ -305,9 +311,6 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
             }
         }
     }
-    STEP_STAMP(3);
-    // ---- the consumed random words are replaced by their successors; the new ring positions
-    if (live) group_finish<W>(R, cfg, p, e, j);
     STEP_STAMP(4);
 }
 
@@ -957,76 +960,98 @@ extern "C" __global__ void k_export_counters(DevCfg cfg, DevPtrs p, int32_t* met
 }
 
 // ------------------------------------------------------------------------------------------------
-// hand-over of the twin MT19937 states, stream-ordered (the facade's global-RNG contract; checkpoints)
+// the bulk ring refill (ctf_mt.h) and the hand-over of the generator states
 // ------------------------------------------------------------------------------------------------
+#define RNG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
+        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define RNG_PAIRS_PER_WAVE 16  // (env, stream) pairs a wave looks after: their flags arrive in one load
+
+// One wave per ring to regenerate: the ring the consumer has left becomes the block after the current one, with its digests, and
+// the current ring is linked to it (mirror, hit bit of its last position).  Envs [e0, e0 + count).  `init`: every stream of
+// the range is treated as not ready and the CURRENT ring's digests are made first (after a seed or a state import).
+// Whole blocks, staged in LDS: 2.5 KB read, 2.5 KB + the digests written per ring, every access of a wave contiguous.
+extern "C" __global__ void __launch_bounds__(256) k_rng_refill(DevCfg cfg, DevPtrs p, int e0, int count, int init) {
+    __shared__ uint32_t sh[4][2 * CTF_MT_N];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    uint32_t* src = sh[wave];
+    uint32_t* dst = src + CTF_MT_N;
+    const int first = (blockIdx.x * 4 + wave) * RNG_PAIRS_PER_WAVE;  // pair t = env e0 + t / 2, stream t % 2
+    if (first >= 2 * count) return;
+    uint32_t rp = 0;
+    bool todo = false;
+    if (lane < RNG_PAIRS_PER_WAVE && first + lane < 2 * count) {
+        rp = p.rngpos[2 * (size_t)e0 + first + lane];
+        todo = init || !CTF_RP_READY(rp);
+    }
+    unsigned long long work = __ballot(todo);
+    while (work) {  // uniform
+        const int k = __ffsll((long long)work) - 1;
+        work &= work - 1;
+        const int t = first + k, e = e0 + (t >> 1), stream = t & 1;
+        const uint32_t rpk = (uint32_t)__shfl((int)rp, k, WAVE);
+        const StreamFull st = stream_full(cfg, p, e, stream, rpk);
+        const uint32_t* gsrc = st.r.raw + st.cur * CTF_MT_N;
+        uint32_t* gdst = st.r.raw + (1 - st.cur) * CTF_MT_N;
+        for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)src)[i] = ((const u32x4_t*)gsrc)[i];
+        RNG_WAVE_SYNC();
+        if (init) ring_digest<WAVE>(lane, src, st.r, (int)st.cur, st.q);
+        ring_next_block<WAVE>(lane, src, dst, st.q, [] { RNG_WAVE_SYNC(); });
+        for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)gdst)[i] = ((const u32x4_t*)dst)[i];
+        ring_digest<WAVE>(lane, dst, st.r, 1 - (int)st.cur, st.q);
+        ring_link<WAVE>(lane, src, dst, st.r, (int)st.cur, st.q);
+        if (lane == 0) p.rngpos[2 * (size_t)e + stream] = CTF_RP_MAKE(st.pos, st.cur, 1);
+        RNG_WAVE_SYNC();  // the LDS copies are reused by the wave's next ring
+    }
+}
+
 // Standard form per env and generator: 624 state words + the position (0..624), as random.getstate()[1] /
-// np.random.get_state()[1:3] give them.  One block per env: block b handles env e0 + b and record b of the arrays.
-// The conversions to / from the run-ahead ring (ctf_mt.h) are sequential: one thread, on a copy in LDS.
+// np.random.get_state()[1:3] give them — which is what ring `cur` and the stream position ARE.  One block per env: block b
+// handles env e0 + b and record b of the arrays.  An import is followed by k_rng_refill(init) over the same envs.
 extern "C" __global__ void __launch_bounds__(256) k_import_rng(DevCfg cfg, DevPtrs p, const uint32_t* __restrict__ py,
                                                                const uint32_t* __restrict__ np_, int e0) {
-    __shared__ uint32_t a[CTF_MT_N];
-    __shared__ uint32_t sh_pos, sh_save;
     const int e = e0 + (int)blockIdx.x, t = threadIdx.x;
     const uint32_t* src[2] = {py, np_};
     uint32_t* dst[2] = {p.mt_py, p.mt_np};
     for (int k = 0; k < 2; k++) {
         if (!src[k]) continue;  // uniform
         const uint32_t* in = src[k] + (size_t)blockIdx.x * (CTF_MT_N + 1);
-        for (int i = t; i < CTF_MT_N; i += blockDim.x) a[i] = in[i];
-        __syncthreads();
-        if (t == 0) {
-            uint32_t sv;
-            sh_pos = mt_std_to_runahead(a, in[CTF_MT_N], &sv);
-            sh_save = sv;
-        }
-        __syncthreads();
-        uint32_t* out = dst[k] + (size_t)e * CTF_MT_STRIDE;
-        for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = a[i];
-        for (int i = t; i < CTF_MT_MIRROR; i += blockDim.x) out[CTF_MT_N + i] = a[i];
-        if (t == 0) {
-            out[CTF_MT_SAVE] = sh_save;
-            p.rngpos[2 * e + k] = sh_pos;
-        }
-        __syncthreads();
+        uint32_t* out = dst[k] + (size_t)e * 2 * CTF_MT_N;
+        for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = in[i];
+        if (t == 0) p.rngpos[2 * e + k] = CTF_RP_MAKE(in[CTF_MT_N] > CTF_MT_N ? CTF_MT_N : in[CTF_MT_N], 0, 0);
     }
 }
 extern "C" __global__ void __launch_bounds__(256) k_export_rng(DevCfg cfg, DevPtrs p, uint32_t* __restrict__ py, uint32_t* __restrict__ np_, int e0) {
-    __shared__ uint32_t a[CTF_MT_N];
-    __shared__ uint32_t sh_pos;
     const int e = e0 + (int)blockIdx.x, t = threadIdx.x;
     uint32_t* dst[2] = {py, np_};
     const uint32_t* src[2] = {p.mt_py, p.mt_np};
     for (int k = 0; k < 2; k++) {
         if (!dst[k]) continue;  // uniform
-        const uint32_t* in = src[k] + (size_t)e * CTF_MT_STRIDE;
-        for (int i = t; i < CTF_MT_N; i += blockDim.x) a[i] = in[i];
-        __syncthreads();
-        if (t == 0) sh_pos = mt_runahead_to_std(a, p.rngpos[2 * e + k], in[CTF_MT_SAVE]);
-        __syncthreads();
+        const uint32_t rp = p.rngpos[2 * e + k];
+        const uint32_t* in = src[k] + ((size_t)e * 2 + CTF_RP_CUR(rp)) * CTF_MT_N;
         uint32_t* out = dst[k] + (size_t)blockIdx.x * (CTF_MT_N + 1);
-        for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = a[i];
-        if (t == 0) out[CTF_MT_N] = sh_pos;
-        __syncthreads();
+        for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = in[i];
+        if (t == 0) out[CTF_MT_N] = CTF_RP_POS(rp);
     }
 }
 // counter mode: (words consumed from the `random` stream, ... from the np.random stream) of every env
 extern "C" __global__ void k_get_counters(DevCfg cfg, DevPtrs p, unsigned long long* out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.n_envs) return;
-    out[2 * (size_t)e] = p.rngctr[4 * (size_t)e];
-    out[2 * (size_t)e + 1] = p.rngctr[4 * (size_t)e + 1];
+    for (int k = 0; k < 2; k++) out[2 * (size_t)e + k] = p.rngctr[4 * (size_t)e + k] + CTF_RP_POS(p.rngpos[2 * e + k]);
 }
-// ... and the way back (a checkpoint restore): the rings are refilled from the given word indices
+// ... and the way back (a checkpoint restore; followed by k_rng_refill(init)): ring 0 = the block that holds word n
 extern "C" __global__ void k_set_counters(DevCfg cfg, DevPtrs p, const unsigned long long* in) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.n_envs) return;
     unsigned long long* ctr = p.rngctr + 4 * (size_t)e;
-    ctr[0] = in[2 * (size_t)e];
-    ctr[1] = in[2 * (size_t)e + 1];
-    ctr_fill_ring(p.mt_py + (size_t)e * CTF_MT_STRIDE, ctr[2], 0u, ctr[0]);
-    ctr_fill_ring(p.mt_np + (size_t)e * CTF_MT_STRIDE, ctr[3], 1u, ctr[1]);
-    p.rngpos[2 * e] = 0;
-    p.rngpos[2 * e + 1] = 0;
+    for (int k = 0; k < 2; k++) {
+        const unsigned long long n = in[2 * (size_t)e + k], blk = n / CTF_MT_N;
+        ctr[k] = blk * CTF_MT_N;
+        uint32_t* a = (k ? p.mt_np : p.mt_py) + (size_t)e * 2 * CTF_MT_N;
+        for (unsigned long long b = 0; b < CTF_MT_N / 4; b++) ctr_block(ctr[2 + k], blk * (CTF_MT_N / 4) + b, (uint32_t)k, a + 4 * b);
+        p.rngpos[2 * e + k] = CTF_RP_MAKE((uint32_t)(n - blk * CTF_MT_N), 0, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1181,6 +1206,11 @@ extern "C" hipError_t ctf_launch_import_rng(const DevCfg& cfg, const DevPtrs& p,
 }
 extern "C" hipError_t ctf_launch_export_rng(const DevCfg& cfg, const DevPtrs& p, uint32_t* py, uint32_t* np_, int e0, int count, hipStream_t st) {
     hipLaunchKernelGGL(k_export_rng, dim3(count), dim3(256), 0, st, cfg, p, py, np_, e0);
+    return hipGetLastError();
+}
+extern "C" hipError_t ctf_launch_rng_refill(const DevCfg& cfg, const DevPtrs& p, int e0, int count, int init, hipStream_t st) {
+    const int waves = (2 * count + RNG_PAIRS_PER_WAVE - 1) / RNG_PAIRS_PER_WAVE;
+    hipLaunchKernelGGL(k_rng_refill, dim3((waves + 3) / 4), dim3(256), 0, st, cfg, p, e0, count, init);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_get_counters(const DevCfg& cfg, const DevPtrs& p, unsigned long long* out, hipStream_t st) {

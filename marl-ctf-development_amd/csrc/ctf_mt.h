@@ -1,30 +1,29 @@
-// ctf_mt.h — MT19937 in RUN-AHEAD form: the per-env state array always holds the NEXT 624 raw (untempered) outputs.
+// ctf_mt.h — the two per-env random streams as the step kernel sees them: RINGS of raw words + DIGESTS of what a step needs.
 //
-// The reference draws from two process-global MT19937 generators (CPython `random`, NumPy legacy `np.random`;
-// reference gridworld_ctf.py:740,771,815).  The standard representation (624 words of block B + a position p) needs
-// a[i], a[i+1], a[i+397] to be combined ("twisted") before word i of block B+1 can be output, i.e. a dependent memory
-// round trip in the middle of whatever consumes the numbers.  Here the array is kept one whole block AHEAD of the
-// consumer instead:
+// The reference draws from two process-global MT19937 generators (CPython `random`: the shuffles, reference
+// gridworld_ctf.py:740; NumPy legacy `np.random`: rand() per opponent :815 and randint() :771).  An MT19937 block of 624
+// words is a function of the block before it (a[i] <- twist(a[i], a[i+1], a[i+397])), so somebody has to do that
+// regeneration — three loads, a store and a dozen operations per word — and with it inside the step kernel every step
+// paid a dependent memory round trip per 16 words (round 2) or ~0.5 KB of scattered loads and stores per env (the first
+// version of round 3).  Now the step kernel regenerates nothing:
 //
-//     a[i], i in [pos, 624)  = raw word i of block B        (not consumed yet)
-//     a[i], i in [0, pos)    = raw word i of block B + 1    (not consumed yet either)
+//   per env and stream, TWO rings of 624 raw words: ring `cur` holds block B (the consumer stands at `pos` in it, exactly
+//   the standard (state, position) form of random.getstate() / np.random.get_state()), the other ring holds block B + 1;
+//   per ring, DIGESTS of its words — everything the step kernel ever looks at:
+//     np.random:  hit bit per position p (rand() drawn from words p, p + 1 is < TAG_PROBABILITY) and the low 4 bits of the
+//                 tempered word (all a randint() over a <= 9-cell spawn window needs);
+//     random:     the top byte of the tempered word (_randbelow(n) for n <= 16 takes its top <= 5 bits);
+//   the digest arrays of a ring end with a MIRROR of the head of the other ring's digests, so that a window that runs over the
+//   end of the block is still one contiguous load.
 //
-// so the next outputs are temper(a[pos]), temper(a[pos+1]), ... (wrapping to a[0]) with no arithmetic in front of them,
-// and a consumer that took w words replaces exactly those w words by their successors one block later
-// (a[i] <- twist(a[i], a[i+1], a[i+397]), in stream order: the standard in-place regeneration, merely delayed by 624
-// words).  That replacement has no consumer inside the step, so it runs at the tail of the step kernel.
+// A step loads ~128 digest bytes per env with three load instructions and stores two positions.  When the consumer leaves a
+// ring, a bulk kernel (k_rng_refill, one wave per ring, every few steps) regenerates it from the ring that is current now —
+// whole blocks, fully coalesced, 8 bytes of traffic per word — and writes its digests.  ring_refill below is that
+// regeneration, written once for 64 lanes (the bulk kernel, staging in LDS), for one lane (the step kernel's safety net, should a
+// ring ever be needed before the bulk kernel got to it) and for the host (tests/hostsim).
 //
-// Array layout per env and stream (u32 words, CTF_MT_STRIDE of them):
-//     [0, 624)                      the ring above
-//     [624, 624 + CTF_MT_MIRROR)    copy of words [0, CTF_MT_MIRROR): every span a kernel reads is contiguous
-//     [CTF_MT_SAVE]                 the raw word 0 of the block BEFORE the one a[0] belongs to (see below)
-//
-// Conversion to / from the standard form (random.getstate() / np.random.get_state()):
-//   std -> run-ahead: the first p iterations of the standard in-place regeneration (all 624 when p == 624).
-//   run-ahead -> std: those iterations are undone.  The regeneration step is invertible: word i of the new block fixes the
-//   top bit of old word i and the low 31 bits of old word i + 1; only the low 31 bits of old word 0 never enter any later
-//   output — they are kept in a[CTF_MT_SAVE] so that the round trip is exact to the last bit.  pos == 0 is reported as the
-//   equivalent standard state (previous block, 624), which is what CPython / NumPy hold after a block's last word.
+// Counter mode (CTF_RNG_COUNTER): the same rings and digests, but block k of a stream is words [624 k, 624 k + 624) of
+// Philox4x32-10(key = the stream's seed, counter = (word / 4, stream, "CTF1")) and the words are used as they are (no tempering).
 #pragma once
 #include <stdint.h>
 
@@ -36,9 +35,18 @@
 #define CTF_HD static inline
 #endif
 
-#define CTF_MT_MIRROR 200  // >= the longest span any kernel reads past a start index < 624 (193 words: W = 8, 12 chunks)
-#define CTF_MT_SAVE 828    // word index of the saved "old word 0"
-#define CTF_MT_STRIDE 832  // words per env and stream (a multiple of 32: arrays start on 128-byte lines)
+// digest array sizes per ring, in dwords (ring + mirror of the other ring's head)
+#define CTF_HB_DW 26    // np hit bits: 624 + 208 bits (a 128-bit window from dword pos >> 5 <= 19 ends at dword 22)
+#define CTF_NB_DW 92    // np nibbles: 624 + 112 nibbles (a 12-dword window from dword pos >> 3 <= 78 ends at dword 89)
+#define CTF_P8_DW 176   // py top bytes: 624 + 80 bytes (a 16-dword window from dword pos >> 2 <= 156 ends at dword 171)
+#define CTF_HB_MIRROR 208
+#define CTF_NB_MIRROR 112
+#define CTF_P8_MIRROR 80
+// rngpos word of a stream: position 0..624 | current ring << 16 | other ring ready << 17
+#define CTF_RP_POS(x) ((x) & 0xFFFFu)
+#define CTF_RP_CUR(x) (((x) >> 16) & 1u)
+#define CTF_RP_READY(x) (((x) >> 17) & 1u)
+#define CTF_RP_MAKE(pos, cur, ready) ((uint32_t)(pos) | ((uint32_t)(cur) << 16) | ((uint32_t)(ready) << 17))
 
 CTF_HD uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);
@@ -52,37 +60,124 @@ CTF_HD uint32_t mt_twist(uint32_t x0, uint32_t x1, uint32_t m) {
     const uint32_t y = (x0 & 0x80000000u) | (x1 & 0x7fffffffu);
     return m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-// the inverse: from a new word and its partner m -> (top bit of old word i) | (low 31 bits of old word i + 1)
-CTF_HD uint32_t mt_untwist(uint32_t v, uint32_t m) {
-    uint32_t y = v ^ m;
-    const uint32_t odd = y >> 31;  // (y >> 1) has a clear top bit, the magic constant a set one
-    if (odd) y ^= 0x9908b0dfu;
-    return (y << 1) | odd;
+
+CTF_HD void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+#define CTF_CTR_TAG 0x43544631u
+// the four words 4 blk .. 4 blk + 3 of counter stream `stream` (0 random, 1 np.random) of seed `seed`
+CTF_HD void ctr_block(unsigned long long seed, unsigned long long blk, uint32_t stream, uint32_t* out) {
+    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)blk, (uint32_t)(blk >> 32), stream, CTF_CTR_TAG, out);
 }
 
-// Standard form (a[0..624) = block B, position p in 0..624) -> run-ahead form, in place (sequential; a may be LDS or host memory).
-// Returns the run-ahead position (0..623) and leaves the word for a[CTF_MT_SAVE] in *save0.
-CTF_HD uint32_t mt_std_to_runahead(uint32_t* a, uint32_t p, uint32_t* save0) {
-    *save0 = a[0];
-    const uint32_t n = p > CTF_MT_N ? CTF_MT_N : p;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t i1 = (i + 1 == CTF_MT_N) ? 0u : i + 1;
-        const uint32_t im = (i + 397 >= CTF_MT_N) ? i + 397 - CTF_MT_N : i + 397;
-        a[i] = mt_twist(a[i], a[i1], a[im]);
+// np.random.rand() < p on the 53-bit integer of the draw: (a >> 5) * 2^26 + (b >> 6) < thr, thr = ceil(p * 2^53) split at bit 26
+CTF_HD bool mt_lt53(uint32_t hi27, uint32_t lo26, uint32_t th, uint32_t tl) { return hi27 < th || (hi27 == th && lo26 < tl); }
+
+struct RingPtrs {       // one env, one stream
+    uint32_t* raw;      // [2][624]
+    uint32_t* hit;      // [2][CTF_HB_DW]   (np stream only)
+    uint32_t* nib;      // [2][CTF_NB_DW]   (np stream only)
+    uint32_t* top;      // [2][CTF_P8_DW]   (py stream only)
+};
+struct RingParams {
+    int stream;                 // 0 random (py), 1 np.random
+    int counter_mode;
+    uint32_t th, tl;            // np: the tag threshold
+    unsigned long long seed;    // counter mode
+    unsigned long long nbase;   // counter mode: stream index of word 0 of the SOURCE ring
+};
+CTF_HD uint32_t ring_out(const RingParams& q, uint32_t w) { return q.counter_mode ? w : mt_temper(w); }
+
+// Digests of the 624 words `w` (ring r of the env): everything but the hit bit of position 623, which needs the next block.
+// Lane `lane` of LANES takes every LANES-th digest dword.
+template <int LANES>
+CTF_HD void ring_digest(int lane, const uint32_t* w, const RingPtrs& p, int r, const RingParams& q) {
+    if (q.stream == 1) {
+        uint32_t* hit = p.hit + r * CTF_HB_DW;
+        for (int d = lane; d < (CTF_MT_N + 31) / 32; d += LANES) {
+            uint32_t bits = 0;
+            uint32_t t0 = ring_out(q, w[32 * d]);
+            for (int k = 0; k < 32 && 32 * d + k < CTF_MT_N - 1; k++) {
+                const uint32_t t1 = ring_out(q, w[32 * d + k + 1]);
+                bits |= (mt_lt53(t0 >> 5, t1 >> 6, q.th, q.tl) ? 1u : 0u) << k;
+                t0 = t1;
+            }
+            hit[d] = bits;  // (dword 19: position 623 and the mirror above it are written by ring_link, once the next block exists)
+        }
+        uint32_t* nib = p.nib + r * CTF_NB_DW;
+        for (int d = lane; d < CTF_MT_N / 8; d += LANES) {
+            uint32_t v = 0;
+            for (int k = 0; k < 8; k++) v |= (ring_out(q, w[8 * d + k]) & 15u) << (4 * k);
+            nib[d] = v;
+        }
+    } else {
+        uint32_t* top = p.top + r * CTF_P8_DW;
+        for (int d = lane; d < CTF_MT_N / 4; d += LANES) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) v |= (ring_out(q, w[4 * d + k]) >> 24) << (8 * k);
+            top[d] = v;
+        }
     }
-    return n == CTF_MT_N ? 0u : n;
 }
-// Run-ahead form -> standard form, in place (sequential).  Returns the standard position (1..624).
-CTF_HD uint32_t mt_runahead_to_std(uint32_t* a, uint32_t pos, uint32_t save0) {
-    const uint32_t n = pos == 0 ? (uint32_t)CTF_MT_N : pos;
-    for (uint32_t i = n; i-- > 0;) {
-        // partner: old word i + 397 (untouched if >= n, else already recovered: its two halves came from steps i + 397 and
-        // i + 396, both behind us) or new word i - 227 (not reached yet)
-        const uint32_t m = (i < CTF_MT_N - 397) ? a[i + 397] : a[i - (CTF_MT_N - 397)];
-        const uint32_t y = mt_untwist(a[i], m);
-        if (i + 1 < n) a[i + 1] = (a[i + 1] & 0x80000000u) | (y & 0x7fffffffu);
-        a[i] = y & 0x80000000u;  // the low bits follow from step i - 1
+// Links ring `c` to its successor ring `o`: the mirror behind ring c's digests = the digests of the head of ring o, and the hit
+// bit of ring c's last position (its rand() takes ring o's first word).  wc / wo: the two rings' words.  Everything is worked out
+// from the words (nothing another lane has just stored is read back).
+template <int LANES>
+CTF_HD void ring_link(int lane, const uint32_t* wc, const uint32_t* wo, const RingPtrs& p, int c, const RingParams& q) {
+    if (q.stream == 1) {
+        uint32_t* hc = p.hit + c * CTF_HB_DW;
+        // dwords 19 .. 25 of ring c's hit array: positions 608 .. 831, i.e. ring c's own last 16 and ring o's first 208
+        for (int d = lane; d < CTF_HB_DW - (CTF_MT_N >> 5); d += LANES) {
+            uint32_t bits = 0;
+            for (int k = 0; k < 32; k++) {
+                const int pc = 32 * ((CTF_MT_N >> 5) + d) + k;  // position counted from ring c's start
+                const uint32_t w0 = pc < CTF_MT_N ? wc[pc] : wo[pc - CTF_MT_N];
+                const uint32_t w1 = pc + 1 < CTF_MT_N ? wc[pc + 1] : wo[pc + 1 - CTF_MT_N];
+                bits |= (mt_lt53(ring_out(q, w0) >> 5, ring_out(q, w1) >> 6, q.th, q.tl) ? 1u : 0u) << k;
+            }
+            hc[(CTF_MT_N >> 5) + d] = bits;
+        }
+        uint32_t* nc = p.nib + c * CTF_NB_DW;
+        for (int d = lane; d < CTF_NB_MIRROR / 8; d += LANES) {
+            uint32_t v = 0;
+            for (int k = 0; k < 8; k++) v |= (ring_out(q, wo[8 * d + k]) & 15u) << (4 * k);
+            nc[CTF_MT_N / 8 + d] = v;
+        }
+    } else {
+        uint32_t* tc = p.top + c * CTF_P8_DW;
+        for (int d = lane; d < CTF_P8_MIRROR / 4; d += LANES) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) v |= (ring_out(q, wo[4 * d + k]) >> 24) << (8 * k);
+            tc[CTF_MT_N / 4 + d] = v;
+        }
     }
-    a[0] = (a[0] & 0x80000000u) | (save0 & 0x7fffffffu);
-    return n;
+}
+// The block after `src` (624 words) into `dst` (624 words; must not alias src).  Three dependent chunks (word i >= 227 takes the
+// NEW word i - 227): `sync` separates them.
+template <int LANES, typename Sync>
+CTF_HD void ring_next_block(int lane, const uint32_t* src, uint32_t* dst, const RingParams& q, Sync sync) {
+    if (q.counter_mode) {
+        for (int b = lane; b < CTF_MT_N / 4; b += LANES) {
+            uint32_t o[4];
+            ctr_block(q.seed, (q.nbase + CTF_MT_N) / 4 + (unsigned long long)b, (uint32_t)q.stream, o);  // nbase is a multiple of 624 = 4 * 156
+            dst[4 * b] = o[0]; dst[4 * b + 1] = o[1]; dst[4 * b + 2] = o[2]; dst[4 * b + 3] = o[3];
+        }
+        sync();
+        return;
+    }
+    for (int i = lane; i < 227; i += LANES) dst[i] = mt_twist(src[i], src[i + 1], src[i + 397]);
+    sync();
+    for (int i = 227 + lane; i < 454; i += LANES) dst[i] = mt_twist(src[i], src[i + 1], dst[i - 227]);
+    sync();
+    for (int i = 454 + lane; i < CTF_MT_N - 1; i += LANES) dst[i] = mt_twist(src[i], src[i + 1], dst[i - 227]);
+    if (lane == 0) dst[CTF_MT_N - 1] = mt_twist(src[CTF_MT_N - 1], dst[0], dst[396]);
+    sync();
 }

@@ -64,14 +64,20 @@ class VecGridworldCtf:
     """
 
     def __init__(self, n_envs, device=None, py_seeds=None, np_seeds=None, log_metrics=True, tune_placement=None, _lib=None,
-                 **env_kwargs):
+                 rng_mode="mt19937", **env_kwargs):
         """tune_placement: pick the observation buffer among a few candidate allocations by timing the render into each
         (default: on for batches whose observation block exceeds 256 MiB).  On MI355X about half of all large hipMalloc
         allocations stream 20 % slower than the others (6.5 vs 5.3 TB/s for a bare store stream into the very same
         virtual address range after a free / re-allocate: it is the physical backing, tools/alloc_probe.hip)."""
         torch = _torch()
         self._lib = _lib or _abi.load_library()  # _lib: a side-by-side build, profiling only (tools/ab_inproc.py)
-        self.cfg, self.derived = _config.build_config(env_kwargs, log_metrics=log_metrics)
+        if rng_mode not in ("mt19937", "counter"):
+            raise ValueError("rng_mode must be 'mt19937' (the reference's generators, bit for bit) or 'counter'")
+        # "counter": opt-in counter-based streams (include/ctf_env.h CTF_RNG_COUNTER) — word n of an env's stream is
+        # Philox4x32-10(seed, n); the draws are made from those words by the reference's own rules
+        self.rng_mode = rng_mode
+        self.cfg, self.derived = _config.build_config(env_kwargs, log_metrics=log_metrics,
+                                                      rng_mode=_abi.RNG_COUNTER if rng_mode == "counter" else _abi.RNG_MT19937)
         if not torch.cuda.is_available():
             raise _abi.CtfLibraryError("no HIP device visible: the GridworldCtf kernels need a GPU (there is no CPU fallback)")
         if device is None:
@@ -201,7 +207,7 @@ class VecGridworldCtf:
     def seed(self, py_seeds=None, np_seeds=None):
         py = _as_seed_array(py_seeds, self.n_envs)
         npz = _as_seed_array(np_seeds if np_seeds is not None else py_seeds, self.n_envs)
-        if (npz >> np.uint64(32)).any():
+        if self.rng_mode == "mt19937" and (npz >> np.uint64(32)).any():
             raise ValueError("Seed must be between 0 and 2**32 - 1")  # np.random.seed's own message
         _abi.check(self._lib.ctf_seed(self._h, py.ctypes.data_as(C.c_void_p), npz.ctypes.data_as(C.c_void_p), self._stream()), self._lib)
         _torch().cuda.current_stream(self.device).synchronize()  # host seed arrays may go away
@@ -232,6 +238,18 @@ class VecGridworldCtf:
         _abi.check(self._lib.ctf_get_rng_states(self._h, None if a is None else C.c_void_p(a.data_ptr()),
                                                 None if b is None else C.c_void_p(b.data_ptr()), self._stream()), self._lib)
         return a, b
+
+    def get_rng_counters(self):
+        """counter mode: int64 CUDA tensor [E, 2] = words consumed so far from the `random` / np.random stream of every env (the
+        whole RNG state of an env there, besides its two seeds).  Stream-ordered."""
+        out = _torch().empty((self.n_envs, 2), dtype=_torch().int64, device=self.device)
+        _abi.check(self._lib.ctf_get_rng_counters(self._h, C.c_void_p(out.data_ptr()), self._stream()), self._lib)
+        return out
+
+    def set_rng_counters(self, counters):
+        """counter mode: the way back (int64 CUDA tensor [E, 2]) — a checkpoint restore after ``seed``."""
+        ptr = self._check_dev(counters, _torch().int64, self.n_envs * 2)
+        _abi.check(self._lib.ctf_set_rng_counters(self._h, ptr, self._stream()), self._lib)
 
     # -- the hot path -------------------------------------------------------------------------
     def reset(self, mask=None):

@@ -44,6 +44,8 @@ def lib():
         L.octf_seed.argtypes = [P, C.c_uint64, C.c_uint64]
         L.octf_set_rng_state.argtypes = [P, P, P]
         L.octf_get_rng_state.argtypes = [P, P, P]
+        L.octf_get_rng_counters.argtypes = [P, P]
+        L.octf_set_rng_counters.argtypes = [P, P]
         L.octf_reset.argtypes = [P]
         L.octf_step.restype = C.c_uint32
         L.octf_step.argtypes = [P, P, P, P]
@@ -95,6 +97,12 @@ class OracleEnv:
         b = np.zeros(625, np.uint32)
         lib().octf_get_rng_state(self._h, _ptr(a), _ptr(b))
         return a, b
+
+    def get_rng_counters(self):
+        """counter mode: (words consumed from the `random` tape, ... from the np.random tape)"""
+        a = np.zeros(2, np.uint64)
+        lib().octf_get_rng_counters(self._h, _ptr(a))
+        return int(a[0]), int(a[1])
 
     def reset(self):
         lib().octf_reset(self._h)

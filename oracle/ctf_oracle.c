@@ -23,7 +23,14 @@
 typedef struct {
     uint32_t mt[CTF_MT_N];
     uint32_t pos;
+    /* counter mode (ctf_env.h CTF_RNG_COUNTER): the "generator" is a tape — word n = Philox4x32-10(key = seed, counter =
+     * (n / 4, stream, "CTF1"))[n % 4], read by the same three functions below (py_randbelow, np_rand, np_randint), i.e. the
+     * reference's random.shuffle / np.random.rand / np.random.randint with their word source patched to the tape */
+    int counter_mode;
+    uint32_t stream;
+    uint64_t seed, n;
 } mt_t;
+static void philox4x32_10(uint32_t ctr[4], uint32_t k0, uint32_t k1);
 
 static void mt_init_genrand(mt_t* g, uint32_t s) {
     g->mt[0] = s;
@@ -54,6 +61,11 @@ static void mt_init_by_array(mt_t* g, const uint32_t* key, int len) {
 
 static uint32_t mt_next(mt_t* g) {
     uint32_t* mt = g->mt;
+    if (g->counter_mode) {
+        uint32_t ctr[4] = {(uint32_t)(g->n >> 2), (uint32_t)((g->n >> 2) >> 32), g->stream, 0x43544631u};
+        philox4x32_10(ctr, (uint32_t)g->seed, (uint32_t)(g->seed >> 32));
+        return ctr[g->n++ & 3u];
+    }
     if (g->pos >= CTF_MT_N) {
         int kk;
         uint32_t y;
@@ -159,11 +171,21 @@ octf_env* octf_create(const ctf_config* cfg) {
 void octf_destroy(octf_env* e) { free(e); }
 
 void octf_seed(octf_env* e, uint64_t py_seed, uint64_t np_seed) {
+    if (e->cfg.rng_mode == CTF_RNG_COUNTER) { /* both tapes from word 0 */
+        e->py.counter_mode = e->np.counter_mode = 1;
+        e->py.stream = 0; e->np.stream = 1;
+        e->py.seed = py_seed; e->np.seed = np_seed;
+        e->py.n = e->np.n = 0;
+        return;
+    }
+    e->py.counter_mode = e->np.counter_mode = 0;
     uint32_t key[2] = {(uint32_t)py_seed, (uint32_t)(py_seed >> 32)};
     mt_init_by_array(&e->py, key, key[1] ? 2 : 1); /* CPython random_seed: 32-bit chunks of abs(seed) */
     mt_init_genrand(&e->np, (uint32_t)np_seed);      /* NumPy _legacy_seeding(int) */
 }
 
+void octf_get_rng_counters(const octf_env* e, uint64_t* out2) { out2[0] = e->py.n; out2[1] = e->np.n; }
+void octf_set_rng_counters(octf_env* e, const uint64_t* in2) { e->py.n = in2[0]; e->np.n = in2[1]; }
 void octf_set_rng_state(octf_env* e, const uint32_t* py_mt625, const uint32_t* np_mt625) {
     if (py_mt625) { memcpy(e->py.mt, py_mt625, 4 * CTF_MT_N); e->py.pos = py_mt625[CTF_MT_N]; }
     if (np_mt625) { memcpy(e->np.mt, np_mt625, 4 * CTF_MT_N); e->np.pos = np_mt625[CTF_MT_N]; }

@@ -27,6 +27,9 @@ void octf_destroy(octf_env* e);
 void octf_seed(octf_env* e, uint64_t py_seed, uint64_t np_seed);
 void octf_set_rng_state(octf_env* e, const uint32_t* py_mt625, const uint32_t* np_mt625);
 void octf_get_rng_state(const octf_env* e, uint32_t* py_mt625, uint32_t* np_mt625);
+/* counter mode (cfg.rng_mode == CTF_RNG_COUNTER): words consumed from the two tapes */
+void octf_get_rng_counters(const octf_env* e, uint64_t* out2);
+void octf_set_rng_counters(octf_env* e, const uint64_t* in2);
 
 void octf_reset(octf_env* e);
 /* returns CTF_ST_* bits raised by this step */

@@ -6,9 +6,9 @@
 // of the product (nothing in marl-ctf-development_amd/ builds, loads or calls it) and it is not the oracle (it is the thing
 // being checked).  Cross-lane behaviour (W > 1: ballots, the slot -> lane rotation) is only covered on the GPU.
 //
-// Build flags let a test shrink the windows so that the rare paths run all the time: -DNP_CH_MAX=1 -DNP_SLACK=0 (the hit-bit
-// window covers almost nothing: direct loads), -DPY_RING=4 -DPY_EXT=2 (the shuffle ring reloads constantly), -DPROD_TQ=1
-// (production in many batches).
+// Build flags let a test shrink the digest windows so that the rare paths run all the time: -DNP_HIT_USABLE=9 -DNP_NIB_USABLE=3
+// -DPY_TOP_USABLE=5 (almost every digest comes straight from memory); and hs_set_refill_every(h, 0) leaves ALL ring
+// regeneration to the step's own safety net (ring_make_ready).
 #define CTF_HOSTSIM 1
 #include <cstdarg>
 #include <cstdio>
@@ -31,19 +31,49 @@ struct hs_env {
     DevCfg d;
     DevPtrs p;
     std::vector<uint8_t> grid, rec, init_grid;
-    std::vector<uint32_t> mt_py, mt_np, rngpos, vis, status;
+    std::vector<uint32_t> mt_py, mt_np, py_top, np_hit, np_nib, rngpos, vis, status;
     std::vector<unsigned long long> rngctr;
     std::vector<int32_t> metrics;
     std::vector<uint16_t> vislog;
     std::vector<uint32_t> lds;
+    int refill_every, steps_since_refill;
 };
+
+static void stream_of(hs_env* h, int e, int stream, StreamFull* st) { *st = stream_full(h->d, h->p, e, stream, h->p.rngpos[2 * e + stream]); }
+
+// what k_rng_refill does for one env and stream: the ring the consumer has left becomes the block after the current one
+static void refill_one(hs_env* h, int e, int stream) {
+    StreamFull st;
+    stream_of(h, e, stream, &st);
+    if (st.ready) return;
+    const uint32_t* src = st.r.raw + st.cur * CTF_MT_N;
+    uint32_t* dst = st.r.raw + (1 - st.cur) * CTF_MT_N;
+    ring_next_block<1>(0, src, dst, st.q, [] {});
+    ring_digest<1>(0, dst, st.r, 1 - (int)st.cur, st.q);
+    ring_link<1>(0, src, dst, st.r, (int)st.cur, st.q);
+    h->p.rngpos[2 * e + stream] = CTF_RP_MAKE(st.pos, st.cur, 1);
+}
+// ... and what the import path does: the current ring's own digests first
+static void init_stream(hs_env* h, int e, int stream, uint32_t pos) {
+    h->p.rngpos[2 * e + stream] = CTF_RP_MAKE(pos, 0, 0);
+    StreamFull st;
+    stream_of(h, e, stream, &st);
+    ring_digest<1>(0, st.r.raw, st.r, 0, st.q);
+    refill_one(h, e, stream);
+}
 
 // k_step<METRICS, 1> for every env: staging, group_step, write-back, group_finish
 template <bool METRICS>
 static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags) {
     const DevCfg& d = h->d;
-    const int GW = d.GS / 4, RW = d.RS / 4, AW = 4, WW = PY_RING, N = d.N;
+    const int GW = d.GS / 4, RW = d.RS / 4, AW = 4, WW = STEP_RNG_WORDS, N = d.N;
     uint32_t* lds = h->lds.data();
+    if (h->refill_every > 0 && h->steps_since_refill >= h->refill_every) {  // ctf_step's cadence of the bulk refill
+        for (int e = 0; e < d.n_envs; e++)
+            for (int k = 0; k < 2; k++) refill_one(h, e, k);
+        h->steps_since_refill = 0;
+    }
+    h->steps_since_refill++;
     for (int e = 0; e < d.n_envs; e++) {
         const uint32_t rp_py = h->p.rngpos[2 * e], rp_np = h->p.rngpos[2 * e + 1];
         GroupRng<1> R;
@@ -53,16 +83,16 @@ static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64
         memset(lds + GW + RW, 0, 16);
         memcpy(lds + GW + RW, actions + (size_t)e * N, (size_t)N);
         if (METRICS) memset(lds + GW + RW + AW + WW, 0, (size_t)((CTF_N_METRICS * N + 3) & ~3));
-        group_step<METRICS, 1>(R, d, h->p, (uint8_t*)lds, e, 0, 0, rp_py, rp_np, flags, rw32, rw64, done);
+        group_step<METRICS, 1>(R, d, h->p, (uint8_t*)lds, e, 0, 0, flags, rw32, rw64, done);
         memcpy(h->grid.data() + (size_t)e * d.GS, lds, (size_t)d.GS);
         memcpy(h->rec.data() + (size_t)e * d.RS, lds + GW, (size_t)d.RS);
         if (METRICS) {
             const uint8_t* dl = (const uint8_t*)(lds + GW + RW + AW + WW);
             for (int w = 0; w < CTF_N_METRICS * N; w++) h->metrics[(size_t)e * CTF_N_METRICS * N + w] += dl[w];
         }
-        group_finish<1>(R, d, h->p, e, 0);
     }
 }
+
 extern "C" {
 
 const char* hs_last_error(void) { return g_err; }
@@ -77,9 +107,14 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
     h->rec.assign(E * d.RS, 0);
     h->init_grid.assign((size_t)d.GS, 0);
     memcpy(h->init_grid.data(), cfg->init_grid, (size_t)d.GG);
-    h->mt_py.assign(E * CTF_MT_STRIDE, 0);
-    h->mt_np.assign(E * CTF_MT_STRIDE, 0);
+    h->mt_py.assign(E * 2 * CTF_MT_N, 0);
+    h->mt_np.assign(E * 2 * CTF_MT_N, 0);
+    h->py_top.assign(E * 2 * CTF_P8_DW, 0xA5A5A5A5u);  // garbage until written: a digest read before its time shows
+    h->np_hit.assign(E * 2 * CTF_HB_DW, 0xA5A5A5A5u);
+    h->np_nib.assign(E * 2 * CTF_NB_DW, 0xA5A5A5A5u);
     h->rngpos.assign(E * 2, 0);
+    h->refill_every = h->d.rng_refill_every;
+    h->steps_since_refill = 0;
     h->rngctr.assign(E * 4, 0);
     h->metrics.assign(E * CTF_N_METRICS * d.N, 0);
     h->vis.assign(E * d.N * d.GS, 0);
@@ -89,6 +124,7 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
     h->p.grid = h->grid.data(); h->p.rec = h->rec.data();
     h->p.mt_py = h->mt_py.data(); h->p.mt_np = h->mt_np.data();
     h->p.rngpos = h->rngpos.data(); h->p.rngctr = h->rngctr.data();
+    h->p.py_top = h->py_top.data(); h->p.np_hit = h->np_hit.data(); h->p.np_nib = h->np_nib.data();
     h->p.metrics = h->metrics.data(); h->p.vis = h->vis.data(); h->p.vislog = h->vislog.data();
     h->p.init_grid = h->init_grid.data(); h->p.meta_lut = nullptr; h->p.status = h->status.data();
     for (size_t e = 0; e < E; e++) {  // k_reset with init_perm
@@ -101,57 +137,71 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
 }
 void hs_destroy(hs_env* h) { delete h; }
 
-static void finish_layout(uint32_t* a, uint32_t save0) {
-    for (int i = 0; i < CTF_MT_MIRROR; i++) a[CTF_MT_N + i] = a[i];
-    a[CTF_MT_SAVE] = save0;
-}
-// standard form (624 words + position) in: what k_import_rng does
+void hs_set_refill_every(hs_env* h, int32_t n) { h->refill_every = n; }
+
+// standard form (624 words + position) in: what ctf_set_rng_state does
 void hs_set_rng_state(hs_env* h, int32_t e, const uint32_t* py, const uint32_t* np_) {
     const uint32_t* src[2] = {py, np_};
     uint32_t* dst[2] = {h->p.mt_py, h->p.mt_np};
     for (int k = 0; k < 2; k++) {
         if (!src[k]) continue;
-        uint32_t* a = dst[k] + (size_t)e * CTF_MT_STRIDE;
-        memcpy(a, src[k], CTF_MT_N * 4);
-        uint32_t sv;
-        h->p.rngpos[2 * e + k] = mt_std_to_runahead(a, src[k][CTF_MT_N], &sv);
-        finish_layout(a, sv);
+        memcpy(dst[k] + (size_t)e * 2 * CTF_MT_N, src[k], CTF_MT_N * 4);
+        init_stream(h, e, k, src[k][CTF_MT_N]);
     }
 }
-// ... and out: what k_export_rng does
+// ... and out: the current ring IS the standard form
 void hs_get_rng_state(hs_env* h, int32_t e, uint32_t* py, uint32_t* np_) {
     uint32_t* dst[2] = {py, np_};
     const uint32_t* src[2] = {h->p.mt_py, h->p.mt_np};
     for (int k = 0; k < 2; k++) {
         if (!dst[k]) continue;
-        const uint32_t* a = src[k] + (size_t)e * CTF_MT_STRIDE;
-        memcpy(dst[k], a, CTF_MT_N * 4);
-        dst[k][CTF_MT_N] = mt_runahead_to_std(dst[k], h->p.rngpos[2 * e + k], a[CTF_MT_SAVE]);
+        const uint32_t rp = h->p.rngpos[2 * e + k];
+        memcpy(dst[k], src[k] + ((size_t)e * 2 + CTF_RP_CUR(rp)) * CTF_MT_N, CTF_MT_N * 4);
+        dst[k][CTF_MT_N] = CTF_RP_POS(rp);
     }
 }
-// the mirror must equal the ring's first words at every kernel boundary: returns the number of violations
-int32_t hs_check_mirror(hs_env* h) {
+// every digest that may be read must be what its ring's words say: returns the number of violations
+int32_t hs_check_digests(hs_env* h) {
     int32_t bad = 0;
     for (int e = 0; e < h->d.n_envs; e++)
         for (int k = 0; k < 2; k++) {
-            const uint32_t* a = (k ? h->p.mt_np : h->p.mt_py) + (size_t)e * CTF_MT_STRIDE;
-            for (int i = 0; i < CTF_MT_MIRROR; i++) bad += a[CTF_MT_N + i] != a[i];
+            StreamFull st;
+            stream_of(h, e, k, &st);
+            for (int which = 0; which < (st.ready ? 2 : 1); which++) {
+                const int r = which ? 1 - (int)st.cur : (int)st.cur;
+                const uint32_t* w = st.r.raw + r * CTF_MT_N;
+                const uint32_t* wn = st.r.raw + (1 - r) * CTF_MT_N;  // the block after ring cur is the other ring (when ready)
+                const int n_pos = (which == 0 && st.ready) ? CTF_MT_N + 64 : CTF_MT_N - 1;  // positions whose digests must be valid
+                for (int i = 0; i < n_pos; i++) {
+                    const uint32_t t0 = ring_out(st.q, i < CTF_MT_N ? w[i] : wn[i - CTF_MT_N]);
+                    const uint32_t t1 = ring_out(st.q, i + 1 < CTF_MT_N ? w[i + 1] : wn[i + 1 - CTF_MT_N]);
+                    if (k == 1) {
+                        const uint32_t hit = (st.r.hit[r * CTF_HB_DW + (i >> 5)] >> (i & 31)) & 1u;
+                        const uint32_t nib = (st.r.nib[r * CTF_NB_DW + (i >> 3)] >> (4 * (i & 7))) & 15u;
+                        bad += hit != (mt_lt53(t0 >> 5, t1 >> 6, st.q.th, st.q.tl) ? 1u : 0u);
+                        bad += nib != (t0 & 15u);
+                    } else {
+                        bad += ((st.r.top[r * CTF_P8_DW + (i >> 2)] >> (8 * (i & 3))) & 255u) != (t0 >> 24);
+                    }
+                }
+            }
         }
     return bad;
 }
-// counter mode: what k_seed does there
+// counter mode: what ctf_seed does there
 void hs_seed_counter(hs_env* h, int32_t e, uint64_t py_seed, uint64_t np_seed) {
     const uint64_t seeds[2] = {py_seed, np_seed};
     for (int k = 0; k < 2; k++) {
-        uint32_t* a = (k ? h->p.mt_np : h->p.mt_py) + (size_t)e * CTF_MT_STRIDE;
+        uint32_t* a = (k ? h->p.mt_np : h->p.mt_py) + (size_t)e * 2 * CTF_MT_N;
         for (unsigned long long blk = 0; blk < CTF_MT_N / 4; blk++) ctr_block(seeds[k], blk, (uint32_t)k, a + 4 * blk);
-        finish_layout(a, 0u);
-        h->p.rngpos[2 * e + k] = 0;
         h->p.rngctr[4 * e + k] = 0;
         h->p.rngctr[4 * e + 2 + k] = seeds[k];
+        init_stream(h, e, k, 0);
     }
 }
-void hs_get_counters(hs_env* h, int32_t e, uint64_t* out) { out[0] = h->p.rngctr[4 * e]; out[1] = h->p.rngctr[4 * e + 1]; }
+void hs_get_counters(hs_env* h, int32_t e, uint64_t* out) {
+    for (int k = 0; k < 2; k++) out[k] = h->p.rngctr[4 * e + k] + CTF_RP_POS(h->p.rngpos[2 * e + k]);
+}
 
 void hs_reset(hs_env* h, int32_t e) {  // k_reset
     const DevCfg& d = h->d;

@@ -32,8 +32,9 @@ def load(path):
     L.hs_last_error.restype = C.c_char_p
     L.hs_set_rng_state.argtypes = [P, C.c_int32, P, P]
     L.hs_get_rng_state.argtypes = [P, C.c_int32, P, P]
-    L.hs_check_mirror.restype = C.c_int32
-    L.hs_check_mirror.argtypes = [P]
+    L.hs_check_digests.restype = C.c_int32
+    L.hs_check_digests.argtypes = [P]
+    L.hs_set_refill_every.argtypes = [P, C.c_int32]
     L.hs_seed_counter.argtypes = [P, C.c_int32, C.c_uint64, C.c_uint64]
     L.hs_get_counters.argtypes = [P, C.c_int32, P]
     L.hs_reset.argtypes = [P, C.c_int32]
@@ -91,7 +92,7 @@ KEYS = ("grid", "pos", "hp", "has_flag", "inv", "perm", "metrics")
 
 def compare(sim, refs, alive, actions, t, ctx, g, auto_reset, check_rng=True):
     status = sim.step(actions, auto_reset)
-    assert sim.L.hs_check_mirror(sim.h) == 0, f"{ctx} step {t}: ring mirror out of sync"
+    assert sim.L.hs_check_digests(sim.h) == 0, f"{ctx} step {t}: a digest does not match its ring"
     for e, r in enumerate(refs):
         if not alive[e]:
             continue
@@ -119,9 +120,35 @@ def compare(sim, refs, alive, actions, t, ctx, g, auto_reset, check_rng=True):
     return status
 
 
-def run_case(L, name, cfg, g, n_envs, steps, seed0, auto_reset, tag):
+def run_counter_case(L, name, cfg, g, n_envs, steps, seed0, tag, refill_every=None):
+    """counter mode: the oracle's shuffle / rand / randint read the same Philox tape; the words consumed must agree too"""
     n = cfg.n_agents
     sim = HostSim(L, cfg, n_envs)
+    if refill_every is not None:
+        L.hs_set_refill_every(sim.h, refill_every)
+    refs = [oracle.OracleEnv(cfg) for _ in range(n_envs)]
+    for e, r in enumerate(refs):
+        r.seed(seed0 + 31 * e, (seed0 + 31 * e) ^ 0xABCDEF0123)
+        L.hs_seed_counter(sim.h, e, seed0 + 31 * e, (seed0 + 31 * e) ^ 0xABCDEF0123)
+    alive = np.ones(n_envs, bool)
+    arng = np.random.default_rng(seed0 + 1)
+    for t in range(steps):
+        actions = arng.integers(0, 9, (n_envs, n)).astype(np.int8)
+        compare(sim, refs, alive, actions, t, f"{tag} {name} (counter)", g, True, check_rng=False)
+        for e, r in enumerate(refs):
+            if alive[e]:
+                c = np.zeros(2, np.uint64)
+                L.hs_get_counters(sim.h, e, ptr(c))
+                assert (int(c[0]), int(c[1])) == r.get_rng_counters(), f"{tag} {name} (counter) env {e} step {t}: words consumed"
+    print(f"ok {tag} {name} (counter mode): {n_envs} envs x {steps} steps, {int(alive.sum())} alive at the end")
+    sim.close()
+
+
+def run_case(L, name, cfg, g, n_envs, steps, seed0, auto_reset, tag, refill_every=None):
+    n = cfg.n_agents
+    sim = HostSim(L, cfg, n_envs)
+    if refill_every is not None:
+        L.hs_set_refill_every(sim.h, refill_every)
     refs = [oracle.OracleEnv(cfg) for _ in range(n_envs)]
     for e, r in enumerate(refs):
         s = seed0 + 977 * e
@@ -180,6 +207,16 @@ def main():
         case = Case(name)
         cfg, _ = case.config(log_metrics=(name != "arena_stress"))
         run_case(L, name, cfg, case.g, 6 if quick else 9, 90 if quick else 260, 4242, name in ("arena_stress", "arena_random"), tag)
+    # the bulk refill never runs: every ring is regenerated by the step's own safety net, at the last moment
+    for name in ("arena_random", "split_random"):
+        case = Case(name)
+        cfg, _ = case.config()
+        run_case(L, name + " (no bulk refill)", cfg, case.g, 5, 120, 777, True, tag, refill_every=0)
+    # counter mode
+    for name in ("arena_random", "split_random", "arena_stress"):
+        case = Case(name)
+        cfg, _ = cfgmod.build_config(case.kwargs, log_metrics=True, rng_mode=abi.RNG_COUNTER)
+        run_counter_case(L, name, cfg, case.g, 5, 150 if quick else 400, 31337, tag, refill_every=(0 if name == "split_random" else None))
     # random configurations: team sizes up to 8 v 8 (a step then consumes more words than one production batch may hold and more
     # than the hit-bit window covers), types that deal no damage, every flip axis
     shapes = [(5, 2), (6, 4), (9, 8), (12, 16), (16, 16), (10, 12), (7, 6)]

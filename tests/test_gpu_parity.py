@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
-from _cases import Case, abi, case_names, pkg, view_arrays
+from _cases import Case, abi, case_names, cfgmod, pkg, view_arrays
 
 pytestmark = pytest.mark.gpu
 
@@ -201,6 +201,92 @@ def test_every_step_lane_width_matches_the_oracle(name, lanes, monkeypatch):
                     rpy, rnp = refs[e].get_rng_state()
                     assert np.array_equal(py, rpy) and np.array_equal(npw, rnp), f"{name} W={lanes} env {e} step {t}: MT19937 states"
     assert alive.sum() >= (n_envs // 8 if name == "syn_edge_k1" else n_envs // 2)
+    vec.close()
+
+
+def _run_against_oracle(vec, cfg, case, seeds, steps, ctx, np_seeds=None, counters=False):
+    n_envs = vec.n_envs
+    refs = [oracle.OracleEnv(cfg) for _ in range(n_envs)]
+    for e, r in enumerate(refs):
+        r.seed(int(seeds[e]), int((np_seeds if np_seeds is not None else seeds)[e]))
+    acts = torch.empty((n_envs, case.n), dtype=torch.int8, device=vec.device)
+    alive = np.ones(n_envs, bool)
+    for t in range(steps):
+        vec.random_actions(acts, seed=0xFEED, step=t, env_offset=3)
+        vec.step(acts, auto_reset=True, want_f64=True)
+        a, r64, d = acts.cpu().numpy(), vec.rewards64.cpu().numpy(), vec.done.cpu().numpy()
+        for e, r in enumerate(refs):
+            if not alive[e]:
+                continue
+            if r.get_state().done:
+                r.reset()
+            rw, dn, status = r.step(a[e])
+            if status:
+                alive[e] = False
+                continue
+            assert np.array_equal(r64[e], rw) and int(d[e]) == int(dn), f"{ctx} env {e} step {t}"
+        if t % 25 == 24 or t == steps - 1:
+            ctr = vec.get_rng_counters().cpu().numpy() if counters else None
+            for e in range(0, n_envs, 5):
+                if alive[e]:
+                    _state_equal(view_arrays(vec.get_state(e), case.n, case.g), view_arrays(refs[e].get_state(), case.n, case.g), f"{ctx} env {e} step {t}")
+                    if counters:
+                        assert tuple(int(x) for x in ctr[e]) == refs[e].get_rng_counters(), f"{ctx} env {e} step {t}: words consumed"
+                    else:
+                        py, npw = vec.get_rng_state(e)
+                        rpy, rnp = refs[e].get_rng_state()
+                        assert np.array_equal(py, rpy) and np.array_equal(npw, rnp), f"{ctx} env {e} step {t}: MT19937 states"
+    return alive
+
+
+@pytest.mark.parametrize("every", [0, 1, 3])
+def test_bulk_refill_cadence_and_the_step_kernels_safety_net(every, monkeypatch):
+    """The MT19937 blocks are regenerated by the bulk kernel k_rng_refill, launched by the library before every step (1); a
+    step that finds a ring missing regenerates it itself (0: the bulk kernel never runs; 3: it runs late).  Same trajectory,
+    same generator states, across several block boundaries of both generators (624 words: ~10 arena steps of np.random)."""
+    monkeypatch.setenv("CTF_RNG_REFILL_EVERY", str(every))
+    case = Case("arena_stress")
+    n_envs = 130
+    seeds = np.arange(n_envs, dtype=np.uint64) * 59 + 11
+    vec = pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=seeds, **case.kwargs)
+    alive = _run_against_oracle(vec, case.config()[0], case, seeds, 150, f"refill every {every}")
+    assert alive.sum() >= n_envs // 2 and vec.status() == 0
+    vec.close()
+
+
+@pytest.mark.parametrize("name", ["arena_random", "split_random", "arena_stress"])
+def test_counter_rng_mode_matches_the_oracle_reading_the_same_tape(name):
+    """rng_mode="counter": word n of an env's stream is Philox4x32-10(seed, n) and random.shuffle / np.random.rand /
+    np.random.randint draw from those words by their own rules — the oracle's three functions read the same tape (SURVEY 8(a));
+    tests/golden/counter_*.npz pins the same against the reference itself."""
+    case = Case(name)
+    n_envs = 140
+    seeds = np.arange(n_envs, dtype=np.uint64) * 0x9E3779B97F4A7C15 + 77  # any 64-bit values
+    np_seeds = seeds ^ np.uint64(0xABCDEF0123456789)
+    vec = pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=np_seeds, rng_mode="counter", **case.kwargs)
+    cfg, _ = cfgmod.build_config(case.kwargs, log_metrics=True, rng_mode=abi.RNG_COUNTER)
+    alive = _run_against_oracle(vec, cfg, case, seeds, 200, f"counter {name}", np_seeds=np_seeds, counters=True)
+    assert alive.sum() >= n_envs // 2 and vec.status() == 0
+    with pytest.raises(abi.CtfLibraryError):
+        vec.get_rng_state(0)  # there is no MT19937 state to hand over in this mode
+    # a checkpoint of the RNG = the counters: restoring them reproduces the continuation
+    ctr = vec.get_rng_counters().clone()
+    snap = [vec.get_state(e) for e in range(n_envs)]
+    acts = torch.empty((n_envs, case.n), dtype=torch.int8, device=vec.device)
+    outs = []
+    for rep in range(2):
+        if rep:
+            vec.seed(seeds, np_seeds)
+            vec.set_rng_counters(ctr)
+            for e in range(n_envs):
+                vec.set_state(e, snap[e])
+        rows = []
+        for t in range(30):
+            vec.random_actions(acts, seed=0xABC, step=t)
+            vec.step(acts, auto_reset=True, want_f64=True)
+            rows.append(vec.rewards64.clone())
+        outs.append((torch.stack(rows), vec.get_rng_counters().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     vec.close()
 
 

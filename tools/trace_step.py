@@ -2,7 +2,8 @@
 """Phase trace of k_step in the bench's state: builds the library with -DSTEP_TRACE=1 (lane 0 of every block stamps the
 100 MHz wall clock at fixed points of the step), runs the bench protocol for a few steps and prints where one wave's time goes.
 
-    python tools/trace_step.py            (GPU box; AB_BUILD_ONLY=1 prebuilds tools/_ab/libtrace.so in the CPU container)
+    python tools/trace_step.py [extra hipcc flags]     (GPU box; AB_BUILD_ONLY=1 prebuilds tools/_ab/libtrace.so in the CPU container)
+    TRACE_WORKLOAD=split TRACE_ENVS=4096 python tools/trace_step.py
 """
 import ctypes, importlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,20 +12,22 @@ import numpy as np
 pkg = importlib.import_module("marl-ctf-development_amd")
 abi = pkg._abi
 CS = os.path.join(ROOT, "marl-ctf-development_amd", "csrc")
-so = os.path.join(ROOT, "tools", "_ab", "libtrace%s.so" % os.environ.get("STEP_TRACE", "1"))
+so = os.path.join(ROOT, "tools", "_ab", "libtrace%s.so" % os.environ.get("TRACE_TAG", ""))
 if not os.path.exists(so) or os.environ.get("AB_BUILD_ONLY"):
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wl,-Bsymbolic",
-                           "-I" + CS, "-DSTEP_TRACE=" + os.environ.get("STEP_TRACE", "1")] + sys.argv[1:] + ["-shared", "-o", so, os.path.join(CS, "ctf_abi.hip"), os.path.join(CS, "ctf_kernels.hip")])
+                           "-I" + CS, "-DSTEP_TRACE=1"] + sys.argv[1:] + ["-shared", "-o", so, os.path.join(CS, "ctf_abi.hip"), os.path.join(CS, "ctf_kernels.hip")])
 if os.environ.get("AB_BUILD_ONLY"):
     sys.exit(0)
 import torch
 import bench
-E = 65536
-kw = bench.WORKLOADS["arena"][1](pkg)
+E = int(os.environ.get("TRACE_ENVS", 65536))
+wl = os.environ.get("TRACE_WORKLOAD", "arena")
+kw = bench.WORKLOADS[wl][1](pkg)
 lib = abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_",))
 vec = pkg.VecGridworldCtf(E, device=0, tune_placement=False, _lib=lib, **kw)
-acts = torch.empty((64, E, vec.N_AGENTS), dtype=torch.int8, device="cuda")
+N = vec.N_AGENTS
+acts = torch.empty((64, E, N), dtype=torch.int8, device="cuda")
 for t in range(64):
     vec.random_actions(acts[t], seed=0xC7F, step=t)
 vec.observe()
@@ -32,58 +35,62 @@ bench.stagger_phases(vec, torch, 0, kw["GAME_STEPS"])
 raw = ctypes.CDLL(so, mode=ctypes.RTLD_LOCAL)  # same handle: dlopen returns the loaded library
 raw.ctf_debug_step_trace.argtypes = [ctypes.c_void_p]
 acc = []
+n_opp = max(vec.cfg.n_opponents[0], vec.cfg.n_opponents[1])
+lanes = int(os.environ.get("CTF_STEP_W", 0)) or (1 if n_opp <= 1 else 2 if n_opp <= 2 else 4 if n_opp <= 4 else 8)
+nblk = min(8192, (E * lanes + 63) // 64)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+kms = []
 for t in range(40):
+    ev[0].record()
     vec.step(acts[t % 64], auto_reset=True)
+    ev[1].record()
     vec.observe()
     if t >= 8:
         torch.cuda.synchronize()
+        kms.append(ev[0].elapsed_time(ev[1]))
         buf = np.zeros((8192, 40), dtype=np.uint64)
         assert raw.ctf_debug_step_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-        acc.append(buf[:E // 16].astype(np.int64))
-bpc, lpc, lpb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-for lds in (8192, 9920, 10240, 12288):
-    rc = raw.ctf_debug_step_occupancy(lds, ctypes.byref(bpc), ctypes.byref(lpc), ctypes.byref(lpb))
-    print(f"runtime occupancy query: {lds} B of LDS per block -> {bpc.value} blocks per CU (rc {rc}); device LDS per CU {lpc.value}, per block {lpb.value}")
-span = np.zeros((8192, 3), dtype=np.uint64)
-raw.ctf_debug_step_span.argtypes = [ctypes.c_void_p]
-assert raw.ctf_debug_step_span(span.ctypes.data_as(ctypes.c_void_p)) == 0
-span = span[:E // 16].astype(np.int64)
-t0 = span[:, 0].min()
-st, en = (span[:, 0] - t0) / 100.0, (span[:, 1] - t0) / 100.0
-print("last step, all %d blocks: start p0/p50/p90/p99/max = %s us; end p0/p50/p90/max = %s us; life mean %.2f us" % (
-    len(span), np.round(np.percentile(st, [0, 50, 90, 99, 100]), 2), np.round(np.percentile(en, [0, 50, 90, 100]), 2), (en - st).mean()))
-hw = span[:, 2] & 0xFFFFFFFF
-xcc = (span[:, 2] >> 32) & 0xF
-cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
-key = xcc * 1000 + se * 100 + sh * 16 + cu
-u, cnt = np.unique(key, return_counts=True)
-print("distinct (xcc, se, sh, cu):", len(u), " blocks per CU min/mean/max:", cnt.min(), cnt.mean(), cnt.max(), " histogram:", dict(zip(*np.unique(cnt, return_counts=True))))
-late = st > 20
-print("blocks starting later than 20 us:", int(late.sum()))
-if os.environ.get('STEP_TRACE', '1') != '1':
-    sys.exit(0)
+        acc.append(buf[:nblk].astype(np.int64))
 a = np.stack(acc)  # [steps, blocks, stamps]
-names = {0: "start", 1: "staged (loads -> LDS, barrier)", 33: "prologue (positions, reset check, perm / flag bits)", 2: "py refill 1", 3: "shuffle 1", 28: "py refill 2", 29: "shuffle 2", 30: "heal + rewards + vis log",
-         31: "flushes + rngpos", 32: "write-back issued"}
-for k in range(8):
-    names[4 + 3 * k] = f"turn {k}: act"
-    names[5 + 3 * k] = f"turn {k}: tagging"
-    names[6 + 3 * k] = f"turn {k}: metrics"
-order = [0, 1, 33, 2, 3] + [4 + i for i in range(24)] + [28, 29, 30, 31, 32]
-prev = None
-tot = {}
-print("phase                                 mean us   p10    p90   (10 ns ticks of the 100 MHz clock, over steps x blocks)")
+print(f"{wl} {E} envs, {lanes} lanes per env, {nblk} blocks traced; k_step by HIP events (traced build): {np.mean(kms) * 1e3:.1f} us")
+t0 = a[:, :, 0].min(axis=1, keepdims=True)
+st, en = (a[:, :, 0] - t0) / 100.0, (a[:, :, 4] - t0) / 100.0
+print("block start p0/p50/p90/p99/max = %s us; end p50/p90/p99/max = %s us" % (
+    np.round(np.percentile(st, [0, 50, 90, 99, 100]), 2), np.round(np.percentile(en, [50, 90, 99, 100]), 2)))
+hw = a[-1, :, 39]
+xcc, simd, cu, sh, se = (hw >> 32) & 0xF, (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+print("placement of the blocks (last step): distinct CUs %d; blocks per CU min/max %d/%d; per (CU, SIMD) min/max %d/%d" % (
+    len(np.unique(cuid)), np.bincount(cuid).min() if len(cuid) else 0, np.bincount(cuid).max(),
+    np.unique(cuid * 4 + simd, return_counts=True)[1].min(), np.unique(cuid * 4 + simd, return_counts=True)[1].max()))
+q = (4 * np.arange(nblk)) // nblk
+tab = np.zeros((4, 4), int)
+for c in range(4):
+    cnt = np.unique((cuid * 4 + simd)[q == c], return_counts=True)[1]
+    for k in range(1, 5):
+        tab[c, k - 1] = int((cnt == k).sum())
+print("cohort (quarter of the grid) x number of its waves on one SIMD (1..4):", tab.tolist())
+print("first 24 blocks -> (xcc, se, sh, cu, simd):", [(int(xcc[b]), int(se[b]), int(sh[b]), int(cu[b]), int(simd[b])) for b in range(min(24, nblk))])
+turns = min(N, 8)
+names = {0: "start", 1: "staged (loads -> LDS)", 7: "digest windows parked", 5: "reset check, perm / flag bits", 6: "shuffle 1",
+         32: "(turns done)", 33: "shuffle 2", 34: "heal + rewards + vis log + record", 2: "positions stored, LDS sync", 4: "write-back issued"}
+order = [0, 1, 7, 5, 6]
+for k in range(turns):
+    names[8 + 3 * k], names[9 + 3 * k], names[10 + 3 * k] = f"turn {k}: act", f"turn {k}: tagging", f"turn {k}: metrics"
+    order += [8 + 3 * k, 9 + 3 * k, 10 + 3 * k]
+order += [32, 33, 34, 2, 4]
+prev, tot = None, {}
+print("phase                                          mean us   p10    p90    p99")
 for k in order:
     if prev is not None:
         d = (a[:, :, k] - a[:, :, prev]).reshape(-1) / 100.0
-        print(f"{names[k]:36s} {d.mean():7.2f} {np.percentile(d, 10):6.2f} {np.percentile(d, 90):6.2f}")
+        print(f"{names[k]:45s} {d.mean():7.2f} {np.percentile(d, 10):6.2f} {np.percentile(d, 90):6.2f} {np.percentile(d, 99):6.2f}")
         key = names[k].split(": ")[-1] if names[k].startswith("turn") else names[k]
         tot[key] = tot.get(key, 0.0) + d.mean()
     prev = k
 print("sum by kind:", {k: round(v, 2) for k, v in tot.items()})
-life = (a[:, :, 32] - a[:, :, 0]) / 100.0
-print("whole (stamp 0 -> 32): mean %.2f us, p50 %.2f, p90 %.2f, p99 %.2f, max %.2f" % (life.mean(), *np.percentile(life, [50, 90, 99, 100])))
-# where do the slowest 2 % of the waves lose their time against the median half?
+life = (a[:, :, 4] - a[:, :, 0]) / 100.0
+print("whole (stamp 0 -> 4): mean %.2f us, p50 %.2f, p90 %.2f, p99 %.2f, max %.2f" % (life.mean(), *np.percentile(life, [50, 90, 99, 100])))
 thr_hi, thr_lo = np.percentile(life, 98), np.percentile(life, 50)
 slow, fast = life >= thr_hi, life <= thr_lo
 print("slowest 2 %% of the waves (>= %.1f us) against the faster half, per phase:" % thr_hi)
@@ -93,5 +100,5 @@ for k in order:
         d = (a[:, :, k] - a[:, :, prev]) / 100.0
         ds, df = d[slow].mean(), d[fast].mean()
         if abs(ds - df) > 0.3:
-            print(f"  {names[k]:36s} slow {ds:6.2f}  fast {df:6.2f}  (+{ds - df:.2f})")
+            print(f"  {names[k]:45s} slow {ds:6.2f}  fast {df:6.2f}  (+{ds - df:.2f})")
     prev = k
