@@ -16,7 +16,8 @@
 
 extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint64_t*, const uint64_t*, hipStream_t);
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
-extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, hipStream_t);
+extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint32_t, hipStream_t);
+extern "C" int ctf_step_blocks(const DevCfg&);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
@@ -35,20 +36,9 @@ struct ctf_env {
     int n_cus;
     uint64_t* seed_scratch;  // device, 2*E u64
     uint32_t* rng_scratch;   // device, 2 x 625 u32: one env's two generators in the standard form (ctf_set/get_rng_state)
-    int steps_since_refill;  // step launches since the bulk ring refill last ran (ctf_mt.h; cadence d.rng_refill_every)
+    uint32_t step_parity;    // alternates per step launch: which half of p.rng_left it writes (the other half is what its tail blocks read)
+    size_t left_bytes;       // bytes of p.rng_left
 };
-
-// Every step launch goes through here first: the rings the consumers have left are regenerated every rng_refill_every steps, which
-// is always before any of them is needed again (ctf_derive.h; the step kernel has its own safety net all the same).
-static hipError_t before_step(ctf_env* h, hipStream_t st) {
-    hipError_t rc = hipSuccess;
-    if (h->d.rng_refill_every > 0 && h->steps_since_refill >= h->d.rng_refill_every) {
-        rc = ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 0, st);
-        h->steps_since_refill = 0;
-    }
-    h->steps_since_refill++;
-    return rc;
-}
 
 static thread_local char g_err[512] = "";
 
@@ -65,6 +55,12 @@ static int fail(int code, const char* fmt, ...) {
         hipError_t _e = (expr);                                                                  \
         if (_e != hipSuccess) return fail(CTF_E_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
     } while (0)
+
+// After a seed / state import every ring is in place (k_rng_refill(init)): nothing is left over for a tail block.
+static hipError_t rng_fresh(ctf_env* h, hipStream_t st) {
+    h->step_parity = 0;
+    return hipMemsetAsync(h->p.rng_left, 0, h->left_bytes, st);
+}
 
 // remembers and restores the caller's current device
 struct DeviceGuard {
@@ -87,8 +83,8 @@ static void free_all(ctf_env* h) {
     (void)hipFree(h->p.grid); (void)hipFree(h->p.rec); (void)hipFree(h->p.mt_py); (void)hipFree(h->p.mt_np);
     (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis); (void)hipFree(h->p.vislog);
     (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
-    (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch);
-    (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib);
+    (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch); (void)hipFree(h->p.rngready);
+    (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib); (void)hipFree(h->p.rng_left);
     delete h;
 }
 
@@ -108,7 +104,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     memset(&h->p, 0, sizeof(h->p));
     h->seed_scratch = nullptr;
     h->rng_scratch = nullptr;
-    h->steps_since_refill = 0;
+    h->step_parity = 0;
     h->cfg = *cfg; h->d = d; h->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
@@ -124,7 +120,10 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     ALLOC(h->p.py_top, E * 2 * CTF_P8_DW * 4);
     ALLOC(h->p.np_hit, E * 2 * CTF_HB_DW * 4);
     ALLOC(h->p.np_nib, E * 2 * CTF_NB_DW * 4);
+    h->left_bytes = (size_t)2 * ctf_step_blocks(d) * 2 * 8;
+    ALLOC(h->p.rng_left, h->left_bytes);
     ALLOC(h->p.rngpos, E * 2 * 4);
+    ALLOC(h->p.rngready, E * 2);
     ALLOC(h->p.rngctr, (d.rng_mode == CTF_RNG_COUNTER ? E * 4 : 1) * 8);
     ALLOC(h->rng_scratch, 2 * (CTF_MT_N + 1) * 4);
     ALLOC(h->p.metrics, met_elems * 4);
@@ -149,6 +148,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     hipError_t e5 = hipMemset(h->seed_scratch, 0, E * 2 * 8);
     hipError_t e6 = ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, nullptr);
     if (e6 == hipSuccess) e6 = ctf_launch_rng_refill(h->d, h->p, 0, n_envs, 1, nullptr);
+    if (e6 == hipSuccess) e6 = rng_fresh(h, nullptr);
     hipError_t e7 = hipDeviceSynchronize();
     if (e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
         const hipError_t bad = e4 != hipSuccess ? e4 : e5 != hipSuccess ? e5 : e6 != hipSuccess ? e6 : e7;
@@ -186,7 +186,7 @@ extern "C" int ctf_seed(ctf_env* h, const uint64_t* py_seeds, const uint64_t* np
     HIP_TRY(hipMemcpyAsync(h->seed_scratch + E, np_seeds, E * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, st));
     HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, st));  // the blocks after the seeded ones, and all digests
-    h->steps_since_refill = 0;
+    HIP_TRY(rng_fresh(h, st));
     HIP_TRY(hipStreamSynchronize(st));  // the host arrays are the caller's; do not outlive the call
     return CTF_OK;
 }
@@ -215,7 +215,10 @@ extern "C" int ctf_set_rng_state(ctf_env* h, int32_t e, const uint32_t* py, cons
         // the two records are not adjacent when only one is given: one launch per generator
         if (dev[0]) HIP_TRY(ctf_launch_import_rng(h->d, h->p, dev[0], nullptr, e, 1, nullptr));
         if (dev[1]) HIP_TRY(ctf_launch_import_rng(h->d, h->p, nullptr, dev[1], e, 1, nullptr));
-        HIP_TRY(ctf_launch_rng_refill(h->d, h->p, e, 1, 1, nullptr));  // (a stream that was not handed over is simply redone)
+        // every ring of every env is brought up to date (envs other than e: whatever the last step left for the next launch's tail)
+        HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 0, nullptr));
+        HIP_TRY(ctf_launch_rng_refill(h->d, h->p, e, 1, 1, nullptr));  // (a stream of env e that was not handed over is simply redone)
+        HIP_TRY(rng_fresh(h, nullptr));
         HIP_TRY(hipDeviceSynchronize());
     }
     return CTF_OK;
@@ -244,7 +247,7 @@ extern "C" int ctf_set_rng_states(ctf_env* h, const uint32_t* py_dev, const uint
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_import_rng(h->d, h->p, py_dev, np_dev, 0, h->d.n_envs, (hipStream_t)stream));
     HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, (hipStream_t)stream));
-    h->steps_since_refill = 0;
+    HIP_TRY(rng_fresh(h, (hipStream_t)stream));
     return CTF_OK;
 }
 
@@ -271,7 +274,7 @@ extern "C" int ctf_set_rng_counters(ctf_env* h, const uint64_t* counters_dev, vo
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_set_counters(h->d, h->p, (const unsigned long long*)counters_dev, (hipStream_t)stream));
     HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, (hipStream_t)stream));
-    h->steps_since_refill = 0;
+    HIP_TRY(rng_fresh(h, (hipStream_t)stream));
     return CTF_OK;
 }
 
@@ -285,8 +288,8 @@ extern "C" int ctf_reset(ctf_env* h, const uint8_t* mask_dev, void* stream) {
 extern "C" int ctf_step(ctf_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    HIP_TRY(before_step(h, (hipStream_t)stream));
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_parity, (hipStream_t)stream));
+    h->step_parity ^= 1u;
     return CTF_OK;
 }
 
@@ -314,8 +317,8 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
                                 uint16_t* meta, uint32_t reverse_mask, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    HIP_TRY(before_step(h, (hipStream_t)stream));
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_parity, (hipStream_t)stream));
+    h->step_parity ^= 1u;
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;

@@ -154,13 +154,10 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
             !make_fastdiv_strided((uint32_t)d->obs_bytes, (uint64_t)d->tile_k * d->obs_bytes + CTF_OBS_TILE, CTF_OBS_TILE, &d->div_ob_tile))
             d->tile_k = d->tile_tpg = d->tile_bx = d->tile_nb = 0;
     }
-    // the bulk ring refill runs before EVERY step (a step then finds both rings of both streams in place and may draw >= 624 words
-    // from each); tests set 0 = never, which leaves all regeneration to the step kernel's safety net
+    // the rings a step's consumers leave are regenerated at the tail of the next step launch; tests set 0 = never, which leaves all
+    // regeneration to the step kernel's safety net
     d->rng_refill_every = 1;
-    if (const char* ov = getenv("CTF_RNG_REFILL_EVERY")) {
-        const int v = atoi(ov);
-        if (v >= 0 && v <= 64) d->rng_refill_every = v;
-    }
+    if (const char* ov = getenv("CTF_RNG_REFILL_EVERY")) d->rng_refill_every = atoi(ov) != 0;
     if (const char* ov = getenv("CTF_STEP_STAGGER")) {  // profiling knob: 10 ns ticks between the cohorts of k_step
         const int v = atoi(ov);
         if (v >= 0 && v <= 100000) d->step_stagger = v;

@@ -103,14 +103,14 @@ extern "C" __global__ void k_seed(DevCfg cfg, DevPtrs p, const uint64_t* py_seed
         }
         unsigned long long* ctr = p.rngctr + 4 * (size_t)e;
         ctr[0] = 0; ctr[1] = 0; ctr[2] = ps; ctr[3] = ns;
-        p.rngpos[2 * e + 0] = CTF_RP_MAKE(0, 0, 0);
-        p.rngpos[2 * e + 1] = CTF_RP_MAKE(0, 0, 0);
+        p.rngpos[2 * e + 0] = CTF_RP_MAKE(0, 0);
+        p.rngpos[2 * e + 1] = CTF_RP_MAKE(0, 0);
     } else {
         uint32_t key[2] = {(uint32_t)ps, (uint32_t)(ps >> 32)};
         mt_init_by_array(a_py, key, key[1] ? 2 : 1);
         mt_init_genrand(a_np, (uint32_t)ns);
-        p.rngpos[2 * e + 0] = CTF_RP_MAKE(CTF_MT_N, 0, 0);  // both generators start exhausted: the first draw comes from the next block
-        p.rngpos[2 * e + 1] = CTF_RP_MAKE(CTF_MT_N, 0, 0);
+        p.rngpos[2 * e + 0] = CTF_RP_MAKE(CTF_MT_N, 0);  // both generators start exhausted: the first draw comes from the next block
+        p.rngpos[2 * e + 1] = CTF_RP_MAKE(CTF_MT_N, 0);
     }
 }
 
@@ -135,6 +135,102 @@ extern "C" __global__ void __launch_bounds__(WAVE) k_reset(DevCfg cfg, DevPtrs p
         for (int w = lane; w < CTF_N_METRICS * cfg.N; w += WAVE) m[w] = 0;
         // visitation: reset_record flagged the base maps as zero and emptied the log — nothing to clear
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ring regeneration by one wave (ctf_mt.h): used by the tail blocks of k_step and by k_rng_refill
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#define RNG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
+        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// ---- the digests of ctf_mt.h as ONE WAVE makes them, from a block's OUTPUT words (tempered, or as they are in counter mode) in
+// LDS: the hit bits of 64 positions are one ballot, a nibble / top-byte dword is a handful of LDS reads.  (ring_digest /
+// ring_link in ctf_mt.h are the same arithmetic one word at a time: the step kernel's safety net and the host simulator use
+// those, and tests run both against each other through CTF_RNG_REFILL_EVERY.)
+__device__ __forceinline__ void wave_digest(int lane, const uint32_t* T, const RingPtrs& p, int r, const RingParams& q) {
+    if (q.stream == 1) {
+        uint32_t* hit = p.hit + r * CTF_HB_DW;
+#pragma unroll 1
+        for (int c = 0; c < (CTF_MT_N + 63) / 64; c++) {
+            const int i = 64 * c + lane;
+            const bool h = i < CTF_MT_N - 1 && mt_lt53(T[i] >> 5, T[i + 1] >> 6, q.th, q.tl);
+            const unsigned long long m = __ballot(h);
+            if (lane < 2 && 2 * c + lane < (CTF_MT_N + 31) / 32) hit[2 * c + lane] = (uint32_t)(m >> (32 * lane));
+        }
+        uint32_t* nib = p.nib + r * CTF_NB_DW;
+        for (int d = lane; d < CTF_MT_N / 8; d += WAVE) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v |= (T[8 * d + k] & 15u) << (4 * k);
+            nib[d] = v;
+        }
+    } else {
+        uint32_t* top = p.top + r * CTF_P8_DW;
+        for (int d = lane; d < CTF_MT_N / 4; d += WAVE) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (T[4 * d + k] >> 24) << (8 * k);
+            top[d] = v;
+        }
+    }
+}
+// Tc: outputs of ring c (only words 608 .. 623 are read), To: outputs of its successor ring
+__device__ __forceinline__ void wave_link(int lane, const uint32_t* Tc, const uint32_t* To, const RingPtrs& p, int c, const RingParams& q) {
+    if (q.stream == 1) {
+        uint32_t* hc = p.hit + c * CTF_HB_DW;
+        constexpr int P0 = (CTF_MT_N >> 5) * 32;  // 608: the first position of dword 19
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {  // positions 608 .. 863, counted from ring c's start (dwords 19 .. 26: the array ends at 25)
+            const int pc = P0 + 64 * k + lane;
+            const uint32_t w0 = pc < CTF_MT_N ? Tc[pc] : To[pc - CTF_MT_N];
+            const uint32_t w1 = pc + 1 < CTF_MT_N ? Tc[pc + 1] : To[pc + 1 - CTF_MT_N];
+            const unsigned long long m = __ballot(mt_lt53(w0 >> 5, w1 >> 6, q.th, q.tl));
+            const int d = (CTF_MT_N >> 5) + 2 * k + lane;
+            if (lane < 2 && d < CTF_HB_DW) hc[d] = (uint32_t)(m >> (32 * lane));
+        }
+        uint32_t* nc = p.nib + c * CTF_NB_DW;
+        if (lane < CTF_NB_MIRROR / 8) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v |= (To[8 * lane + k] & 15u) << (4 * k);
+            nc[CTF_MT_N / 8 + lane] = v;
+        }
+    } else {
+        uint32_t* tc = p.top + c * CTF_P8_DW;
+        if (lane < CTF_P8_MIRROR / 4) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (To[4 * lane + k] >> 24) << (8 * k);
+            tc[CTF_MT_N / 4 + lane] = v;
+        }
+    }
+}
+
+
+// One ring, one wave: the ring the consumer has left becomes the block after the current one, with its digests, and the current
+// ring is linked to it (mirror, hit bit of its last position).  src / dst: 2 x 624 words of the wave's LDS.  `init`: the CURRENT
+// ring's digests are made too (after a seed or a state import).  2.5 KB read, 2.5 KB + the digests written, every access of the
+// wave contiguous.
+__device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p, int e, int stream, int lane, uint32_t* src, uint32_t* dst,
+                                            bool init) {
+    const StreamFull st = stream_full(cfg, p, e, stream);  // (the position is not looked at: the consumer's launch may be moving it)
+    const uint32_t* gsrc = st.r.raw + st.cur * CTF_MT_N;
+    uint32_t* gdst = st.r.raw + (1 - st.cur) * CTF_MT_N;
+    for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)src)[i] = ((const u32x4_t*)gsrc)[i];
+    RNG_WAVE_SYNC();
+    ring_next_block<WAVE>(lane, src, dst, st.q, [] { RNG_WAVE_SYNC(); });
+    for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)gdst)[i] = ((const u32x4_t*)dst)[i];
+    // the raw words are done with: both LDS copies become OUTPUT words (of ring c only what is looked at)
+    for (int i = lane; i < CTF_MT_N; i += WAVE) {
+        dst[i] = ring_out(st.q, dst[i]);
+        if (init || i >= (CTF_MT_N >> 5) * 32) src[i] = ring_out(st.q, src[i]);
+    }
+    RNG_WAVE_SYNC();
+    if (init) wave_digest(lane, src, st.r, (int)st.cur, st.q);
+    wave_digest(lane, dst, st.r, 1 - (int)st.cur, st.q);
+    wave_link(lane, src, dst, st.r, (int)st.cur, st.q);
+    if (lane == 0) p.rngready[2 * (size_t)e + stream] = 1;
+    RNG_WAVE_SYNC();  // the LDS copies are reused by the wave's next ring
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -164,15 +260,47 @@ extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
 #define STEP_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+#define STEP_TAIL_K 2  // tail blocks per step block (ring regeneration; see k_step)
+
 // 16 blocks (= waves) per CU fit by LDS: the register budget is held to the matching 4 waves per SIMD (128 VGPRs)
 template <bool METRICS, int W>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restrict__ rw32, double* __restrict__ rw64,
-       uint8_t* __restrict__ done_out, uint32_t flags) {
+       uint8_t* __restrict__ done_out, uint32_t flags, uint32_t parity, int n_step_blocks) {
     constexpr int EPW = WAVE / W;  // envs per wave
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_step_blocks) {
+        // ---- a TAIL block: regenerates rings that consumers left during the PREVIOUS step launch (its step blocks published
+        // which: two lane masks per block, p.rng_left).  STEP_TAIL_K tail blocks share one step block's list.  They start as step
+        // blocks retire (the LDS is full until then) and touch nothing a step block of this launch reads: an env that left a
+        // ring last step stands in the first words of its new block and looks at neither the other ring nor its mirror.
+        const int tb = (int)blockIdx.x - n_step_blocks, sb = tb / STEP_TAIL_K, k0 = tb - sb * STEP_TAIL_K;
+        const unsigned long long* left = p.rng_left + ((size_t)(parity ^ 1u) * n_step_blocks + sb) * 2;
+        unsigned long long m[2] = {left[0], left[1]};
+        int ord = 0;
+        STEP_STAMP(0);
+        int n_done = 0;
+#pragma unroll 1
+        for (int stream = 0; stream < 2; stream++) {
+            while (m[stream]) {  // uniform
+                const int bit = __ffsll((long long)m[stream]) - 1;
+                m[stream] &= m[stream] - 1;
+                if ((ord++ % STEP_TAIL_K) != k0) continue;
+                const int e = sb * EPW + bit / W;
+                refill_ring(cfg, p, e, stream, lane, lds, lds + CTF_MT_N, false);
+                n_done++;
+            }
+        }
+        STEP_STAMP(4);
+#if STEP_TRACE
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_step_trace[blockIdx.x][5] = (unsigned long long)n_done;
+#else
+        (void)n_done;
+#endif
+        return;
+    }
     STEP_STAMP(0);
 #if STEP_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 8192)
@@ -196,28 +324,31 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
     const int N = cfg.N;
     const int e = env0 + g;
     const bool live = g < nvalid;
+    const int e_ld = live ? e : cfg.n_envs - 1;  // the idle groups of a ragged last block shadow a valid env: every load below is
+                                                 // unconditional, so that the compiler can count them (a load under a branch makes
+                                                 // every later wait a full drain: two serialised round trips instead of one)
     // the two stream positions: the addresses of the step's random digests depend on them, so they go first
-    uint32_t rp_py = 0, rp_np = 0;
-    if (live) {
-        rp_py = p.rngpos[2 * e];
-        rp_np = p.rngpos[2 * e + 1];
-    }
+    const uint32_t rp_py = p.rngpos[2 * e_ld], rp_np = p.rngpos[2 * e_ld + 1];
+    const uint32_t ready2 = *(const uint16_t*)(p.rngready + 2 * (size_t)e_ld);
 
     // ---- stage the wave's envs' grids, records and actions into LDS.  Flat, coalesced 16-byte loads, the first 4 + 2 per lane
-    // issued before anything waits; the random words' loads follow them as soon as the ring positions are there.
+    // issued before anything waits; the digest windows' loads follow them as soon as the stream positions are there.
     const u32x4* gsrc = (const u32x4*)(p.grid + (size_t)env0 * cfg.GS);
     const u32x4* rsrc = (const u32x4*)(p.rec + (size_t)env0 * cfg.RS);
     const int GQ = GW / 4, RQ = RW / 4;  // 16-byte quads per env (GS and RS are multiples of 16)
     const int ng = nvalid * GQ, nr = nvalid * RQ;
     u32x4 gv[4], rv[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-        if (lane + WAVE * u < ng) gv[u] = gsrc[lane + WAVE * u];
+    for (int u = 0; u < 4; u++) gv[u] = gsrc[min(lane + WAVE * u, ng - 1)];
 #pragma unroll
-    for (int u = 0; u < 2; u++)
-        if (lane + WAVE * u < nr) rv[u] = rsrc[lane + WAVE * u];
+    for (int u = 0; u < 2; u++) rv[u] = rsrc[min(lane + WAVE * u, nr - 1)];
+    const int na = nvalid * N;
+    const int8_t* asrc = actions + (size_t)env0 * N;
+    int8_t av[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) av[u] = asrc[min(lane + WAVE * u, na - 1)];
     GroupRng<W> R;
-    if (live) group_issue_loads<W>(R, cfg, p, e, j, rp_py, rp_np);
+    group_issue_loads<W>(R, cfg, p, e_ld, j, live, rp_py, rp_np, ready2);
     {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -249,9 +380,15 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
             uint32_t* slot = lds + el * SLW + GW + w;
             slot[0] = v.x; slot[1] = v.y; slot[2] = v.z; slot[3] = v.w;
         }
-        const int8_t* asrc = actions + (size_t)env0 * N;
-#pragma unroll 2
-        for (int idx = lane; idx < nvalid * N; idx += WAVE) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int idx = lane + WAVE * u;
+            if (idx < na) {
+                const int el = (int)fdiv((uint32_t)idx, cfg.div_n), i = idx - el * N;
+                ((int8_t*)(lds + el * SLW + GW + RW))[i] = av[u];
+            }
+        }
+        for (int idx = lane + WAVE * 2; idx < na; idx += WAVE) {  // W = 1 with N > 2 only
             const int el = (int)fdiv((uint32_t)idx, cfg.div_n), i = idx - el * N;
             ((int8_t*)(lds + el * SLW + GW + RW))[i] = asrc[idx];
         }
@@ -268,7 +405,15 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
     STEP_LDS_SYNC();
     STEP_STAMP(1);
 
-    if (live) group_step<METRICS, W>(R, cfg, p, (uint8_t*)(lds + g * SLW), e, j, g * W, flags, rw32, rw64, done_out);
+    uint32_t left_ring = 0;
+    if (live) group_step<METRICS, W>(R, cfg, p, (uint8_t*)(lds + g * SLW), e, j, g * W, flags, rw32, rw64, done_out, left_ring);
+    {   // which of the wave's envs left a ring of which stream: the next launch's tail blocks regenerate exactly those
+        const unsigned long long m_py = __ballot((left_ring & 1u) != 0), m_np = __ballot((left_ring & 2u) != 0);
+        if (lane == 0) {
+            unsigned long long* left = p.rng_left + ((size_t)parity * n_step_blocks + blockIdx.x) * 2;
+            left[0] = m_py; left[1] = m_np;
+        }
+    }
     STEP_LDS_SYNC();
     STEP_STAMP(2);
 
@@ -356,7 +501,6 @@ template <>
 struct OutVec<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
 template <>
 struct OutVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4), aligned(4))); };
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int flip_cell(const DevCfg& cfg, int cell, int r, int c) {
@@ -962,8 +1106,6 @@ extern "C" __global__ void k_export_counters(DevCfg cfg, DevPtrs p, int32_t* met
 // ------------------------------------------------------------------------------------------------
 // the bulk ring refill (ctf_mt.h) and the hand-over of the generator states
 // ------------------------------------------------------------------------------------------------
-#define RNG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
-        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define RNG_PAIRS_PER_WAVE 16  // (env, stream) pairs a wave looks after: their flags arrive in one load
 
 // One wave per ring to regenerate: the ring the consumer has left becomes the block after the current one, with its digests, and
@@ -978,30 +1120,14 @@ extern "C" __global__ void __launch_bounds__(256) k_rng_refill(DevCfg cfg, DevPt
     uint32_t* dst = src + CTF_MT_N;
     const int first = (blockIdx.x * 4 + wave) * RNG_PAIRS_PER_WAVE;  // pair t = env e0 + t / 2, stream t % 2
     if (first >= 2 * count) return;
-    uint32_t rp = 0;
     bool todo = false;
-    if (lane < RNG_PAIRS_PER_WAVE && first + lane < 2 * count) {
-        rp = p.rngpos[2 * (size_t)e0 + first + lane];
-        todo = init || !CTF_RP_READY(rp);
-    }
+    if (lane < RNG_PAIRS_PER_WAVE && first + lane < 2 * count) todo = init || !p.rngready[2 * (size_t)e0 + first + lane];
     unsigned long long work = __ballot(todo);
     while (work) {  // uniform
         const int k = __ffsll((long long)work) - 1;
         work &= work - 1;
         const int t = first + k, e = e0 + (t >> 1), stream = t & 1;
-        const uint32_t rpk = (uint32_t)__shfl((int)rp, k, WAVE);
-        const StreamFull st = stream_full(cfg, p, e, stream, rpk);
-        const uint32_t* gsrc = st.r.raw + st.cur * CTF_MT_N;
-        uint32_t* gdst = st.r.raw + (1 - st.cur) * CTF_MT_N;
-        for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)src)[i] = ((const u32x4_t*)gsrc)[i];
-        RNG_WAVE_SYNC();
-        if (init) ring_digest<WAVE>(lane, src, st.r, (int)st.cur, st.q);
-        ring_next_block<WAVE>(lane, src, dst, st.q, [] { RNG_WAVE_SYNC(); });
-        for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)gdst)[i] = ((const u32x4_t*)dst)[i];
-        ring_digest<WAVE>(lane, dst, st.r, 1 - (int)st.cur, st.q);
-        ring_link<WAVE>(lane, src, dst, st.r, (int)st.cur, st.q);
-        if (lane == 0) p.rngpos[2 * (size_t)e + stream] = CTF_RP_MAKE(st.pos, st.cur, 1);
-        RNG_WAVE_SYNC();  // the LDS copies are reused by the wave's next ring
+        refill_ring(cfg, p, e, stream, lane, src, dst, init != 0);
     }
 }
 
@@ -1018,7 +1144,7 @@ extern "C" __global__ void __launch_bounds__(256) k_import_rng(DevCfg cfg, DevPt
         const uint32_t* in = src[k] + (size_t)blockIdx.x * (CTF_MT_N + 1);
         uint32_t* out = dst[k] + (size_t)e * 2 * CTF_MT_N;
         for (int i = t; i < CTF_MT_N; i += blockDim.x) out[i] = in[i];
-        if (t == 0) p.rngpos[2 * e + k] = CTF_RP_MAKE(in[CTF_MT_N] > CTF_MT_N ? CTF_MT_N : in[CTF_MT_N], 0, 0);
+        if (t == 0) p.rngpos[2 * e + k] = CTF_RP_MAKE(in[CTF_MT_N] > CTF_MT_N ? CTF_MT_N : in[CTF_MT_N], 0);
     }
 }
 extern "C" __global__ void __launch_bounds__(256) k_export_rng(DevCfg cfg, DevPtrs p, uint32_t* __restrict__ py, uint32_t* __restrict__ np_, int e0) {
@@ -1050,7 +1176,7 @@ extern "C" __global__ void k_set_counters(DevCfg cfg, DevPtrs p, const unsigned 
         ctr[k] = blk * CTF_MT_N;
         uint32_t* a = (k ? p.mt_np : p.mt_py) + (size_t)e * 2 * CTF_MT_N;
         for (unsigned long long b = 0; b < CTF_MT_N / 4; b++) ctr_block(ctr[2 + k], blk * (CTF_MT_N / 4) + b, (uint32_t)k, a + 4 * b);
-        p.rngpos[2 * e + k] = CTF_RP_MAKE((uint32_t)(n - blk * CTF_MT_N), 0, 0);
+        p.rngpos[2 * e + k] = CTF_RP_MAKE((uint32_t)(n - blk * CTF_MT_N), 0);
     }
 }
 
@@ -1095,19 +1221,21 @@ extern "C" hipError_t ctf_launch_reset(const DevCfg& cfg, const DevPtrs& p, cons
 }
 template <bool METRICS, int W>
 static void launch_step_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done,
-                          uint32_t flags, hipStream_t st) {
+                          uint32_t flags, uint32_t parity, hipStream_t st) {
     constexpr int EPW = WAVE / W;
-    const dim3 grid((cfg.n_envs + EPW - 1) / EPW), block(WAVE);
-    const size_t sh = (size_t)EPW * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
-    hipLaunchKernelGGL((k_step<METRICS, W>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags);
+    const int nstep = (cfg.n_envs + EPW - 1) / EPW;
+    const dim3 grid(nstep * (cfg.rng_refill_every ? 1 + STEP_TAIL_K : 1)), block(WAVE);
+    size_t sh = (size_t)EPW * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
+    if (sh < 2 * CTF_MT_N * 4) sh = 2 * CTF_MT_N * 4;  // a tail block stages two rings
+    hipLaunchKernelGGL((k_step<METRICS, W>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags, parity, nstep);
 }
 template <bool METRICS>
 static void launch_step_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                          uint8_t* done, uint32_t flags, hipStream_t st) {
-    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, st);
-    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, st);
-    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, st);
-    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, st);
+                          uint8_t* done, uint32_t flags, uint32_t parity, hipStream_t st) {
+    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
+    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
+    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
+    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
 }
 // lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn
 static int step_lanes(const DevCfg& cfg) {
@@ -1116,13 +1244,15 @@ static int step_lanes(const DevCfg& cfg) {
     if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling knob (CTF_STEP_W), results are identical
     return w;
 }
+// parity: alternates from one step launch to the next (which half of p.rng_left this launch writes)
 extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                                      uint8_t* done, uint32_t flags, hipStream_t st) {
+                                      uint8_t* done, uint32_t flags, uint32_t parity, hipStream_t st) {
     const int w = step_lanes(cfg);
-    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, st);
-    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, st);
+    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, parity, st);
+    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, parity, st);
     return hipGetLastError();
 }
+extern "C" int ctf_step_blocks(const DevCfg& cfg) { return (cfg.n_envs + WAVE / step_lanes(cfg) - 1) / (WAVE / step_lanes(cfg)); }
 #if STEP_TRACE
 // what the runtime thinks fits: blocks of k_step<true, 4> per CU at `lds` bytes of dynamic LDS, and the device's LDS per CU
 extern "C" int ctf_debug_step_occupancy(int lds, int* blocks_per_cu, int* lds_per_cu, int* lds_per_block) {

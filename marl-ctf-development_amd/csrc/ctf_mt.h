@@ -42,11 +42,12 @@
 #define CTF_HB_MIRROR 208
 #define CTF_NB_MIRROR 112
 #define CTF_P8_MIRROR 80
-// rngpos word of a stream: position 0..624 | current ring << 16 | other ring ready << 17
+// rngpos word of a stream: position 0..624 | current ring << 16.  Whether the OTHER ring is in place (regenerated and linked) is
+// a byte of its own, rngready: the consumer's launch writes the position, the regenerating wave — possibly of the same launch —
+// the flag.
 #define CTF_RP_POS(x) ((x) & 0xFFFFu)
 #define CTF_RP_CUR(x) (((x) >> 16) & 1u)
-#define CTF_RP_READY(x) (((x) >> 17) & 1u)
-#define CTF_RP_MAKE(pos, cur, ready) ((uint32_t)(pos) | ((uint32_t)(cur) << 16) | ((uint32_t)(ready) << 17))
+#define CTF_RP_MAKE(pos, cur) ((uint32_t)(pos) | ((uint32_t)(cur) << 16))
 
 CTF_HD uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);

@@ -30,16 +30,18 @@ static int fail(int code, const char* fmt, ...) {
 struct hs_env {
     DevCfg d;
     DevPtrs p;
-    std::vector<uint8_t> grid, rec, init_grid;
+    std::vector<uint8_t> grid, rec, init_grid, rngready;
     std::vector<uint32_t> mt_py, mt_np, py_top, np_hit, np_nib, rngpos, vis, status;
     std::vector<unsigned long long> rngctr;
     std::vector<int32_t> metrics;
     std::vector<uint16_t> vislog;
     std::vector<uint32_t> lds;
-    int refill_every, steps_since_refill;
+    int refill_every;
+    std::vector<uint8_t> left[2];  // per step parity: which rings each env left during that step (bit 0 random, bit 1 np.random)
+    int parity;
 };
 
-static void stream_of(hs_env* h, int e, int stream, StreamFull* st) { *st = stream_full(h->d, h->p, e, stream, h->p.rngpos[2 * e + stream]); }
+static void stream_of(hs_env* h, int e, int stream, StreamFull* st) { *st = stream_full(h->d, h->p, e, stream); }
 
 // what k_rng_refill does for one env and stream: the ring the consumer has left becomes the block after the current one
 static void refill_one(hs_env* h, int e, int stream) {
@@ -51,11 +53,13 @@ static void refill_one(hs_env* h, int e, int stream) {
     ring_next_block<1>(0, src, dst, st.q, [] {});
     ring_digest<1>(0, dst, st.r, 1 - (int)st.cur, st.q);
     ring_link<1>(0, src, dst, st.r, (int)st.cur, st.q);
-    h->p.rngpos[2 * e + stream] = CTF_RP_MAKE(st.pos, st.cur, 1);
+    h->p.rngready[2 * e + stream] = 1;
 }
 // ... and what the import path does: the current ring's own digests first
 static void init_stream(hs_env* h, int e, int stream, uint32_t pos) {
-    h->p.rngpos[2 * e + stream] = CTF_RP_MAKE(pos, 0, 0);
+    h->left[0][e] &= (uint8_t)~(1u << stream); h->left[1][e] &= (uint8_t)~(1u << stream);
+    h->p.rngpos[2 * e + stream] = CTF_RP_MAKE(pos, 0);
+    h->p.rngready[2 * e + stream] = 0;
     StreamFull st;
     stream_of(h, e, stream, &st);
     ring_digest<1>(0, st.r.raw, st.r, 0, st.q);
@@ -68,22 +72,18 @@ static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64
     const DevCfg& d = h->d;
     const int GW = d.GS / 4, RW = d.RS / 4, AW = 4, WW = STEP_RNG_WORDS, N = d.N;
     uint32_t* lds = h->lds.data();
-    if (h->refill_every > 0 && h->steps_since_refill >= h->refill_every) {  // ctf_step's cadence of the bulk refill
-        for (int e = 0; e < d.n_envs; e++)
-            for (int k = 0; k < 2; k++) refill_one(h, e, k);
-        h->steps_since_refill = 0;
-    }
-    h->steps_since_refill++;
     for (int e = 0; e < d.n_envs; e++) {
         const uint32_t rp_py = h->p.rngpos[2 * e], rp_np = h->p.rngpos[2 * e + 1];
         GroupRng<1> R;
-        group_issue_loads<1>(R, d, h->p, e, 0, rp_py, rp_np);
+        group_issue_loads<1>(R, d, h->p, e, 0, true, rp_py, rp_np, (uint32_t)h->p.rngready[2 * e] | ((uint32_t)h->p.rngready[2 * e + 1] << 8));
         memcpy(lds, h->grid.data() + (size_t)e * d.GS, (size_t)d.GS);
         memcpy(lds + GW, h->rec.data() + (size_t)e * d.RS, (size_t)d.RS);
         memset(lds + GW + RW, 0, 16);
         memcpy(lds + GW + RW, actions + (size_t)e * N, (size_t)N);
         if (METRICS) memset(lds + GW + RW + AW + WW, 0, (size_t)((CTF_N_METRICS * N + 3) & ~3));
-        group_step<METRICS, 1>(R, d, h->p, (uint8_t*)lds, e, 0, 0, flags, rw32, rw64, done);
+        uint32_t left_ring = 0;
+        group_step<METRICS, 1>(R, d, h->p, (uint8_t*)lds, e, 0, 0, flags, rw32, rw64, done, left_ring);
+        h->left[h->parity][e] = (uint8_t)left_ring;
         memcpy(h->grid.data() + (size_t)e * d.GS, lds, (size_t)d.GS);
         memcpy(h->rec.data() + (size_t)e * d.RS, lds + GW, (size_t)d.RS);
         if (METRICS) {
@@ -91,6 +91,13 @@ static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64
             for (int w = 0; w < CTF_N_METRICS * N; w++) h->metrics[(size_t)e * CTF_N_METRICS * N + w] += dl[w];
         }
     }
+    // the launch's TAIL blocks: the rings that were left during the PREVIOUS step are regenerated now — after this step's
+    // groups have run without them, which is the latest the real launch can get to them
+    if (h->refill_every)
+        for (int e = 0; e < d.n_envs; e++)
+            for (int k = 0; k < 2; k++)
+                if (h->left[h->parity ^ 1][e] & (1u << k)) refill_one(h, e, k);
+    h->parity ^= 1;
 }
 
 extern "C" {
@@ -113,8 +120,10 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
     h->np_hit.assign(E * 2 * CTF_HB_DW, 0xA5A5A5A5u);
     h->np_nib.assign(E * 2 * CTF_NB_DW, 0xA5A5A5A5u);
     h->rngpos.assign(E * 2, 0);
+    h->rngready.assign(E * 2, 0);
     h->refill_every = h->d.rng_refill_every;
-    h->steps_since_refill = 0;
+    h->left[0].assign(E, 0); h->left[1].assign(E, 0);
+    h->parity = 0;
     h->rngctr.assign(E * 4, 0);
     h->metrics.assign(E * CTF_N_METRICS * d.N, 0);
     h->vis.assign(E * d.N * d.GS, 0);
@@ -123,7 +132,7 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
     h->lds.assign((size_t)step_slot_bytes(d.GS, d.RS, d.N, true) / 4 + 4, 0);
     h->p.grid = h->grid.data(); h->p.rec = h->rec.data();
     h->p.mt_py = h->mt_py.data(); h->p.mt_np = h->mt_np.data();
-    h->p.rngpos = h->rngpos.data(); h->p.rngctr = h->rngctr.data();
+    h->p.rngpos = h->rngpos.data(); h->p.rngctr = h->rngctr.data(); h->p.rngready = h->rngready.data();
     h->p.py_top = h->py_top.data(); h->p.np_hit = h->np_hit.data(); h->p.np_nib = h->np_nib.data();
     h->p.metrics = h->metrics.data(); h->p.vis = h->vis.data(); h->p.vislog = h->vislog.data();
     h->p.init_grid = h->init_grid.data(); h->p.meta_lut = nullptr; h->p.status = h->status.data();

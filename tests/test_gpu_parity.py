@@ -239,17 +239,18 @@ def _run_against_oracle(vec, cfg, case, seeds, steps, ctx, np_seeds=None, counte
     return alive
 
 
-@pytest.mark.parametrize("every", [0, 1, 3])
-def test_bulk_refill_cadence_and_the_step_kernels_safety_net(every, monkeypatch):
-    """The MT19937 blocks are regenerated by the bulk kernel k_rng_refill, launched by the library before every step (1); a
-    step that finds a ring missing regenerates it itself (0: the bulk kernel never runs; 3: it runs late).  Same trajectory,
-    same generator states, across several block boundaries of both generators (624 words: ~10 arena steps of np.random)."""
+@pytest.mark.parametrize("every", [0, 1])
+def test_ring_regeneration_by_the_tail_blocks_and_by_the_safety_net(every, monkeypatch):
+    """The MT19937 blocks are regenerated one launch behind their consumers, by the tail blocks of the next k_step launch (1, the
+    default: whole rings, one wave each); a step that needs a ring that is not there regenerates it itself, one word at a time
+    (0: no tail blocks at all).  Two implementations of the same digests: same trajectory, same generator states, across
+    several block boundaries of both generators (624 words: ~10 arena steps of np.random)."""
     monkeypatch.setenv("CTF_RNG_REFILL_EVERY", str(every))
     case = Case("arena_stress")
     n_envs = 130
     seeds = np.arange(n_envs, dtype=np.uint64) * 59 + 11
     vec = pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=seeds, **case.kwargs)
-    alive = _run_against_oracle(vec, case.config()[0], case, seeds, 150, f"refill every {every}")
+    alive = _run_against_oracle(vec, case.config()[0], case, seeds, 150, f"tail blocks {every}")
     assert alive.sum() >= n_envs // 2 and vec.status() == 0
     vec.close()
 

@@ -50,8 +50,17 @@ for t in range(40):
         kms.append(ev[0].elapsed_time(ev[1]))
         buf = np.zeros((8192, 40), dtype=np.uint64)
         assert raw.ctf_debug_step_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-        acc.append(buf[:nblk].astype(np.int64))
-a = np.stack(acc)  # [steps, blocks, stamps]
+        acc.append(buf[:min(8192, 3 * nblk)].astype(np.int64))
+full = np.stack(acc)  # [steps, blocks incl. tail blocks, stamps]
+if full.shape[1] > nblk:  # the tail blocks (ring regeneration) that fit into the trace buffer
+    tl = full[:, nblk:, :]
+    t00 = full[:, :nblk, 0].min(axis=1, keepdims=True)
+    ts, te, nd = (tl[:, :, 0] - t00) / 100.0, (tl[:, :, 4] - t00) / 100.0, tl[:, :, 5]
+    busy = nd > 0
+    print("tail blocks traced: %d per step; rings per block mean %.2f max %d; start (us after the launch's first block) p10/p50/p90/max %s; end p50/p90/p99/max %s; "
+          "life of a block with work: mean %.2f us, per ring %.2f us" % (tl.shape[1], nd.mean(), nd.max(), np.round(np.percentile(ts, [10, 50, 90, 100]), 1),
+          np.round(np.percentile(te, [50, 90, 99, 100]), 1), (te - ts)[busy].mean(), ((te - ts)[busy] / nd[busy]).mean()))
+a = full[:, :nblk, :]
 print(f"{wl} {E} envs, {lanes} lanes per env, {nblk} blocks traced; k_step by HIP events (traced build): {np.mean(kms) * 1e3:.1f} us")
 t0 = a[:, :, 0].min(axis=1, keepdims=True)
 st, en = (a[:, :, 0] - t0) / 100.0, (a[:, :, 4] - t0) / 100.0
