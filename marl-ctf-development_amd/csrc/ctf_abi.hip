@@ -36,8 +36,7 @@ struct ctf_env {
     int n_cus;
     uint64_t* seed_scratch;  // device, 2*E u64
     uint32_t* rng_scratch;   // device, 2 x 625 u32: one env's two generators in the standard form (ctf_set/get_rng_state)
-    uint32_t step_parity;    // alternates per step launch: which half of p.rng_left it writes (the other half is what its tail blocks read)
-    size_t left_bytes;       // bytes of p.rng_left
+    uint32_t step_phase;     // counts the step launches (k_step's tail blocks: which share of the stale rings this launch takes)
 };
 
 static thread_local char g_err[512] = "";
@@ -57,9 +56,9 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // After a seed / state import every ring is in place (k_rng_refill(init)): nothing is left over for a tail block.
-static hipError_t rng_fresh(ctf_env* h, hipStream_t st) {
-    h->step_parity = 0;
-    return hipMemsetAsync(h->p.rng_left, 0, h->left_bytes, st);
+static hipError_t rng_fresh(ctf_env* h, hipStream_t) {
+    h->step_phase = 0;
+    return hipSuccess;
 }
 
 // remembers and restores the caller's current device
@@ -84,7 +83,7 @@ static void free_all(ctf_env* h) {
     (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis); (void)hipFree(h->p.vislog);
     (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
     (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch); (void)hipFree(h->p.rngready);
-    (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib); (void)hipFree(h->p.rng_left);
+    (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib);
     delete h;
 }
 
@@ -104,7 +103,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     memset(&h->p, 0, sizeof(h->p));
     h->seed_scratch = nullptr;
     h->rng_scratch = nullptr;
-    h->step_parity = 0;
+    h->step_phase = 0;
     h->cfg = *cfg; h->d = d; h->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
@@ -120,11 +119,9 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     ALLOC(h->p.py_top, E * 2 * CTF_P8_DW * 4);
     ALLOC(h->p.np_hit, E * 2 * CTF_HB_DW * 4);
     ALLOC(h->p.np_nib, E * 2 * CTF_NB_DW * 4);
-    h->left_bytes = (size_t)2 * ctf_step_blocks(d) * 2 * 8;
-    ALLOC(h->p.rng_left, h->left_bytes);
     ALLOC(h->p.rngpos, E * 2 * 4);
     ALLOC(h->p.rngready, E * 2);
-    ALLOC(h->p.rngctr, (d.rng_mode == CTF_RNG_COUNTER ? E * 4 : 1) * 8);
+    ALLOC(h->p.rngctr, (d.rng_mode == CTF_RNG_COUNTER ? E * 6 : 1) * 8);
     ALLOC(h->rng_scratch, 2 * (CTF_MT_N + 1) * 4);
     ALLOC(h->p.metrics, met_elems * 4);
     ALLOC(h->p.vis, vis_elems * 4);
@@ -288,8 +285,7 @@ extern "C" int ctf_reset(ctf_env* h, const uint8_t* mask_dev, void* stream) {
 extern "C" int ctf_step(ctf_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_parity, (hipStream_t)stream));
-    h->step_parity ^= 1u;
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, (hipStream_t)stream));
     return CTF_OK;
 }
 
@@ -317,8 +313,7 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
                                 uint16_t* meta, uint32_t reverse_mask, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_parity, (hipStream_t)stream));
-    h->step_parity ^= 1u;
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, (hipStream_t)stream));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;

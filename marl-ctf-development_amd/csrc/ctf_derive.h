@@ -158,6 +158,19 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     // regeneration to the step kernel's safety net
     d->rng_refill_every = 1;
     if (const char* ov = getenv("CTF_RNG_REFILL_EVERY")) d->rng_refill_every = atoi(ov) != 0;
+    {   // A consumer that has just moved to a new block stands in its first `worst` words and needs the block after it once it is
+        // closer than rng_safe_ahead to the end: (624 - ahead - worst) / worst steps later at the earliest.  A stale ring is
+        // regenerated within rng_spread launches, the first of them the launch after (or of) the move.
+        const int worst_np = 2 * d->np_pairs + 32, worst_py = 8 * N + 32;  // words per step, generously
+        const int worst = worst_np > worst_py ? worst_np : worst_py;
+        d->rng_safe_ahead = 192 > worst + 64 ? 192 : worst + 64;  // >= the digest windows' reach (128 + 31) and any step's draws
+        int slack = (CTF_MT_N - d->rng_safe_ahead - worst) / worst;   // whole steps between the move and the first need
+        d->rng_spread = slack < 1 ? 1 : (slack > 4 ? 4 : slack);
+        if (const char* ov = getenv("CTF_RNG_SPREAD")) {
+            const int v = atoi(ov);
+            if (v >= 1 && v <= d->rng_spread) d->rng_spread = v;
+        }
+    }
     if (const char* ov = getenv("CTF_STEP_STAGGER")) {  // profiling knob: 10 ns ticks between the cohorts of k_step
         const int v = atoi(ov);
         if (v >= 0 && v <= 100000) d->step_stagger = v;

@@ -13,8 +13,8 @@
 //   np_hit u32 [E][2][26]     digests of an np.random ring: per position, is the rand() that starts there < TAG_PROBABILITY ...
 //   np_nib u32 [E][2][92]     ... and the low 4 bits of the tempered word (randint over the spawn window); + mirrors
 //   rngpos u32 [E][2]         per stream: position 0..624 in the current ring | current ring << 16
-//   rngready u8 [E][2]        per stream: the other ring is in place (regenerated from the current one and linked to it)
-//   rngctr u64 [E][4]         counter mode only (cfg.rng_mode == 1): stream index of word 0 of the current ring (py, np), seeds (py, np)
+//   rngready u8 [E][2]        per stream: 1 = the other ring is in place; 2 + r = ring r is stale and waits for its regeneration
+//   rngctr u64 [E][6]         counter mode only (cfg.rng_mode == 1): stream index of word 0 of ring 0 / ring 1 (py), of ring 0 / 1 (np), seeds (py, np)
 //   metric i32 [E][13][N]     agent-level counters (only when log_metrics)
 //   vislog u16 [512][E][N]    visitation LOG: entry (step % 512) = the cell of every agent after that step; the
 //                             maps are rebuilt from it on export, so a step writes 2N coalesced bytes per env
@@ -51,6 +51,9 @@ struct DevCfg {
     int32_t step_lanes_override;    // 0 = automatic; set from CTF_STEP_W for profiling
     int32_t rng_refill_every;       // 1: rings are regenerated at the tail of the next step launch (default); 0: never (tests: the
                                     // step kernel's safety net does all the work)
+    int32_t rng_safe_ahead;         // words: a step that starts this far (or further) before the end of its block needs no other ring
+    int32_t rng_spread;             // a stale ring is regenerated within this many launches: a burst of them (the envs' positions
+                                    // move in step) is spread over as many launches
     int32_t step_stagger;           // start offset between the four cohorts of k_step's blocks, in 10 ns ticks (0 = none)
     // np.random.rand() < TAG_PROBABILITY on the 53-bit integer x = (a >> 5) * 2^26 + (b >> 6): x < tag_thr, split at bit 26
     uint32_t tag_th, tag_tl;
@@ -88,11 +91,10 @@ struct DevPtrs {
     uint32_t* mt_np;
     uint32_t* rngpos;
     uint8_t* rngready;
-    unsigned long long* rngctr;  // counter mode: u64 [E][4] = stream index of the current ring's word 0 (py, np), stream seeds (py, np)
+    unsigned long long* rngctr;  // counter mode: u64 [E][6] = stream index of word 0 of each ring (py 0, py 1, np 0, np 1), stream seeds (py, np)
     uint32_t* py_top;
     uint32_t* np_hit;
     uint32_t* np_nib;
-    unsigned long long* rng_left;  // u64 [2][step blocks][2]: per step parity and step block, which lanes' envs left a ring (py, np)
     int32_t* metrics;
     uint32_t* vis;             // base maps u32 [E][N][GS]; valid only when the env's CTF_F_BASE_ZERO flag is clear
     uint16_t* vislog;          // u16 [CTF_VIS_LOG][E][N]

@@ -101,8 +101,8 @@ extern "C" __global__ void k_seed(DevCfg cfg, DevPtrs p, const uint64_t* py_seed
             ctr_block(ps, blk, 0u, a_py + 4 * blk);
             ctr_block(ns, blk, 1u, a_np + 4 * blk);
         }
-        unsigned long long* ctr = p.rngctr + 4 * (size_t)e;
-        ctr[0] = 0; ctr[1] = 0; ctr[2] = ps; ctr[3] = ns;
+        unsigned long long* ctr = p.rngctr + 6 * (size_t)e;
+        ctr[0] = 0; ctr[2] = 0; ctr[4] = ps; ctr[5] = ns;  // ring 0 of either stream starts at word 0
         p.rngpos[2 * e + 0] = CTF_RP_MAKE(0, 0);
         p.rngpos[2 * e + 1] = CTF_RP_MAKE(0, 0);
     } else {
@@ -150,27 +150,40 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wave_digest(int lane, const uint32_t* T, const RingPtrs& p, int r, const RingParams& q) {
     if (q.stream == 1) {
         uint32_t* hit = p.hit + r * CTF_HB_DW;
-#pragma unroll 1
-        for (int c = 0; c < (CTF_MT_N + 63) / 64; c++) {
+        uint32_t t0[10], t1[10];
+#pragma unroll
+        for (int c = 0; c < 10; c++) {  // 624 positions = 10 x 64 (the last 16 lanes of the last pass idle): the reads first
             const int i = 64 * c + lane;
-            const bool h = i < CTF_MT_N - 1 && mt_lt53(T[i] >> 5, T[i + 1] >> 6, q.th, q.tl);
-            const unsigned long long m = __ballot(h);
+            t0[c] = T[i < CTF_MT_N ? i : 0];
+            t1[c] = T[i + 1 < CTF_MT_N ? i + 1 : 0];
+        }
+#pragma unroll
+        for (int c = 0; c < 10; c++) {
+            const int i = 64 * c + lane;
+            const unsigned long long m = __ballot(i < CTF_MT_N - 1 && mt_lt53(t0[c] >> 5, t1[c] >> 6, q.th, q.tl));
             if (lane < 2 && 2 * c + lane < (CTF_MT_N + 31) / 32) hit[2 * c + lane] = (uint32_t)(m >> (32 * lane));
         }
         uint32_t* nib = p.nib + r * CTF_NB_DW;
-        for (int d = lane; d < CTF_MT_N / 8; d += WAVE) {
-            uint32_t v = 0;
+        const u32x4_t* T4 = (const u32x4_t*)T;
 #pragma unroll
-            for (int k = 0; k < 8; k++) v |= (T[8 * d + k] & 15u) << (4 * k);
-            nib[d] = v;
+        for (int it = 0; it < 2; it++) {  // 78 dwords of 8 nibbles
+            const int d = lane + 64 * it;
+            if (d < CTF_MT_N / 8) {
+                const u32x4_t a = T4[2 * d], b = T4[2 * d + 1];
+                nib[d] = (a.x & 15u) | ((a.y & 15u) << 4) | ((a.z & 15u) << 8) | ((a.w & 15u) << 12) | ((b.x & 15u) << 16) | ((b.y & 15u) << 20) |
+                         ((b.z & 15u) << 24) | ((b.w & 15u) << 28);
+            }
         }
     } else {
         uint32_t* top = p.top + r * CTF_P8_DW;
-        for (int d = lane; d < CTF_MT_N / 4; d += WAVE) {
-            uint32_t v = 0;
+        const u32x4_t* T4 = (const u32x4_t*)T;
 #pragma unroll
-            for (int k = 0; k < 4; k++) v |= (T[4 * d + k] >> 24) << (8 * k);
-            top[d] = v;
+        for (int it = 0; it < 3; it++) {  // 156 dwords of 4 top bytes
+            const int d = lane + 64 * it;
+            if (d < CTF_MT_N / 4) {
+                const u32x4_t a = T4[d];
+                top[d] = (a.x >> 24) | ((a.y >> 24) << 8) | ((a.z >> 24) << 16) | ((a.w >> 24) << 24);
+            }
         }
     }
 }
@@ -179,12 +192,16 @@ __device__ __forceinline__ void wave_link(int lane, const uint32_t* Tc, const ui
     if (q.stream == 1) {
         uint32_t* hc = p.hit + c * CTF_HB_DW;
         constexpr int P0 = (CTF_MT_N >> 5) * 32;  // 608: the first position of dword 19
-#pragma unroll 1
+        uint32_t w0[4], w1[4];
+#pragma unroll
         for (int k = 0; k < 4; k++) {  // positions 608 .. 863, counted from ring c's start (dwords 19 .. 26: the array ends at 25)
             const int pc = P0 + 64 * k + lane;
-            const uint32_t w0 = pc < CTF_MT_N ? Tc[pc] : To[pc - CTF_MT_N];
-            const uint32_t w1 = pc + 1 < CTF_MT_N ? Tc[pc + 1] : To[pc + 1 - CTF_MT_N];
-            const unsigned long long m = __ballot(mt_lt53(w0 >> 5, w1 >> 6, q.th, q.tl));
+            w0[k] = pc < CTF_MT_N ? Tc[pc] : To[pc - CTF_MT_N];
+            w1[k] = pc + 1 < CTF_MT_N ? Tc[pc + 1] : To[pc + 1 - CTF_MT_N];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = __ballot(mt_lt53(w0[k] >> 5, w1[k] >> 6, q.th, q.tl));
             const int d = (CTF_MT_N >> 5) + 2 * k + lane;
             if (lane < 2 && d < CTF_HB_DW) hc[d] = (uint32_t)(m >> (32 * lane));
         }
@@ -205,31 +222,94 @@ __device__ __forceinline__ void wave_link(int lane, const uint32_t* Tc, const ui
         }
     }
 }
-
+// the block after `src` into `dst` (both LDS) by one wave: ring_next_block of ctf_mt.h with the three dependent chunks unrolled, every
+// chunk's LDS reads issued before its arithmetic
+__device__ __forceinline__ void wave_next_block(int lane, const uint32_t* src, uint32_t* dst, const RingParams& q) {
+    if (q.counter_mode) {
+#pragma unroll 1
+        for (int b = lane; b < CTF_MT_N / 4; b += WAVE) {
+            uint32_t o[4];
+            ctr_block(q.seed, (q.nbase + CTF_MT_N) / 4 + (unsigned long long)b, (uint32_t)q.stream, o);
+            ((u32x4_t*)dst)[b] = u32x4_t{o[0], o[1], o[2], o[3]};
+        }
+        RNG_WAVE_SYNC();
+        return;
+    }
+    constexpr int M = CTF_MT_N - 397;  // 227
+#pragma unroll
+    for (int chunk = 0; chunk < 3; chunk++) {
+        const int lo = chunk * M, hi = chunk == 2 ? CTF_MT_N - 1 : lo + M;  // [0, 227), [227, 454), [454, 623)
+        uint32_t x0[4], x1[4], m[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int i = lo + lane + 64 * it, ic = i < hi ? i : lo;
+            x0[it] = src[ic];
+            x1[it] = src[ic + 1];
+            m[it] = chunk == 0 ? src[ic + 397] : dst[ic - M];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int i = lo + lane + 64 * it;
+            if (i < hi) dst[i] = mt_twist(x0[it], x1[it], m[it]);
+        }
+        if (chunk == 2 && lane == 0) dst[CTF_MT_N - 1] = mt_twist(src[CTF_MT_N - 1], dst[0], dst[396]);
+        RNG_WAVE_SYNC();
+    }
+}
 
 // One ring, one wave: the ring the consumer has left becomes the block after the current one, with its digests, and the current
 // ring is linked to it (mirror, hit bit of its last position).  src / dst: 2 x 624 words of the wave's LDS.  `init`: the CURRENT
 // ring's digests are made too (after a seed or a state import).  2.5 KB read, 2.5 KB + the digests written, every access of the
 // wave contiguous.
-__device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p, int e, int stream, int lane, uint32_t* src, uint32_t* dst,
-                                            bool init) {
-    const StreamFull st = stream_full(cfg, p, e, stream);  // (the position is not looked at: the consumer's launch may be moving it)
-    const uint32_t* gsrc = st.r.raw + st.cur * CTF_MT_N;
-    uint32_t* gdst = st.r.raw + (1 - st.cur) * CTF_MT_N;
-    for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)src)[i] = ((const u32x4_t*)gsrc)[i];
+__device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p, int e, int stream, uint32_t flag, int lane, uint32_t* src,
+                                            uint32_t* dst, bool init) {
+    StreamFull st = stream_full(cfg, p, e, stream);
+    st.cur = ring_source(flag, p.rngpos[2 * (size_t)e + stream]);  // the flag says which ring is stale (the position word may be moving)
+    ring_counter_params(st.q, p, e, stream, st.cur);
+    const u32x4_t* gsrc = (const u32x4_t*)(st.r.raw + st.cur * CTF_MT_N);
+    u32x4_t* gdst = (u32x4_t*)(st.r.raw + (1 - st.cur) * CTF_MT_N);
+    constexpr int NQ = CTF_MT_N / 4;  // 156 quads: two full passes of the wave and 28 lanes of a third
+    {
+        const u32x4_t a = gsrc[lane], b = gsrc[lane + WAVE], c = gsrc[lane + 2 * WAVE < NQ ? lane + 2 * WAVE : 0];
+        ((u32x4_t*)src)[lane] = a;
+        ((u32x4_t*)src)[lane + WAVE] = b;
+        if (lane + 2 * WAVE < NQ) ((u32x4_t*)src)[lane + 2 * WAVE] = c;
+    }
     RNG_WAVE_SYNC();
-    ring_next_block<WAVE>(lane, src, dst, st.q, [] { RNG_WAVE_SYNC(); });
-    for (int i = lane; i < CTF_MT_N / 4; i += WAVE) ((u32x4_t*)gdst)[i] = ((const u32x4_t*)dst)[i];
-    // the raw words are done with: both LDS copies become OUTPUT words (of ring c only what is looked at)
-    for (int i = lane; i < CTF_MT_N; i += WAVE) {
-        dst[i] = ring_out(st.q, dst[i]);
-        if (init || i >= (CTF_MT_N >> 5) * 32) src[i] = ring_out(st.q, src[i]);
+    wave_next_block(lane, src, dst, st.q);
+    {   // the new block's raw words leave; both LDS copies then become OUTPUT words (of ring c only what is looked at)
+        u32x4_t v[3];
+#pragma unroll
+        for (int it = 0; it < 3; it++) v[it] = ((const u32x4_t*)dst)[lane + WAVE * it < NQ ? lane + WAVE * it : 0];
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int d = lane + WAVE * it;
+            if (d < NQ) {
+                gdst[d] = v[it];
+                ((u32x4_t*)dst)[d] = u32x4_t{ring_out(st.q, v[it].x), ring_out(st.q, v[it].y), ring_out(st.q, v[it].z), ring_out(st.q, v[it].w)};
+            }
+        }
+        if (init) {
+#pragma unroll
+            for (int it = 0; it < 3; it++) {
+                const int d = lane + WAVE * it;
+                if (d < NQ) {
+                    const u32x4_t w = ((const u32x4_t*)src)[d];
+                    ((u32x4_t*)src)[d] = u32x4_t{ring_out(st.q, w.x), ring_out(st.q, w.y), ring_out(st.q, w.z), ring_out(st.q, w.w)};
+                }
+            }
+        } else if (lane < 16) {
+            src[(CTF_MT_N >> 5) * 32 + lane] = ring_out(st.q, src[(CTF_MT_N >> 5) * 32 + lane]);
+        }
     }
     RNG_WAVE_SYNC();
     if (init) wave_digest(lane, src, st.r, (int)st.cur, st.q);
     wave_digest(lane, dst, st.r, 1 - (int)st.cur, st.q);
     wave_link(lane, src, dst, st.r, (int)st.cur, st.q);
-    if (lane == 0) p.rngready[2 * (size_t)e + stream] = 1;
+    if (lane == 0) {
+        ring_counter_store(st.q, p, e, stream, 1u - st.cur);
+        p.rngready[2 * (size_t)e + stream] = 1;
+    }
     RNG_WAVE_SYNC();  // the LDS copies are reused by the wave's next ring
 }
 
@@ -260,38 +340,36 @@ extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
 #define STEP_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-#define STEP_TAIL_K 2  // tail blocks per step block (ring regeneration; see k_step)
+#define STEP_TAIL_PAIRS 16  // (env, stream) pairs a tail block of k_step looks after (ring regeneration)
 
 // 16 blocks (= waves) per CU fit by LDS: the register budget is held to the matching 4 waves per SIMD (128 VGPRs)
 template <bool METRICS, int W>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restrict__ rw32, double* __restrict__ rw64,
-       uint8_t* __restrict__ done_out, uint32_t flags, uint32_t parity, int n_step_blocks) {
+       uint8_t* __restrict__ done_out, uint32_t flags, uint32_t phase, int n_step_blocks) {
     constexpr int EPW = WAVE / W;  // envs per wave
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= n_step_blocks) {
-        // ---- a TAIL block: regenerates rings that consumers left during the PREVIOUS step launch (its step blocks published
-        // which: two lane masks per block, p.rng_left).  STEP_TAIL_K tail blocks share one step block's list.  They start as step
-        // blocks retire (the LDS is full until then) and touch nothing a step block of this launch reads: an env that left a
-        // ring last step stands in the first words of its new block and looks at neither the other ring nor its mirror.
-        const int tb = (int)blockIdx.x - n_step_blocks, sb = tb / STEP_TAIL_K, k0 = tb - sb * STEP_TAIL_K;
-        const unsigned long long* left = p.rng_left + ((size_t)(parity ^ 1u) * n_step_blocks + sb) * 2;
-        unsigned long long m[2] = {left[0], left[1]};
-        int ord = 0;
+        // ---- a TAIL block: regenerates rings whose consumers have moved on (rngready says which).  It looks after STEP_TAIL_PAIRS
+        // (env, stream) pairs; a stale ring of env e is taken by the launch with (e + phase) % rng_spread == 0, because the envs'
+        // stream positions move in step (every env draws the same words per step, give or take a respawn): most of them leave
+        // their block in the same step, and that burst is spread over rng_spread launches — always before the ring is needed.
+        // Tail blocks start as step blocks retire (the LDS is full until then); they touch nothing a step block reads: an env
+        // whose ring is stale stands at the head of its new block and looks at neither the other ring nor its mirror.
+        const int first = ((int)blockIdx.x - n_step_blocks) * STEP_TAIL_PAIRS;
+        uint32_t flag = 1;
+        if (lane < STEP_TAIL_PAIRS && first + lane < 2 * cfg.n_envs) flag = p.rngready[first + lane];
+        const int spread = cfg.rng_spread;
+        unsigned long long work = __ballot(flag >= 2u && (uint32_t)(((first + lane) >> 1) + (int)phase) % (uint32_t)spread == 0u);
         STEP_STAMP(0);
         int n_done = 0;
-#pragma unroll 1
-        for (int stream = 0; stream < 2; stream++) {
-            while (m[stream]) {  // uniform
-                const int bit = __ffsll((long long)m[stream]) - 1;
-                m[stream] &= m[stream] - 1;
-                if ((ord++ % STEP_TAIL_K) != k0) continue;
-                const int e = sb * EPW + bit / W;
-                refill_ring(cfg, p, e, stream, lane, lds, lds + CTF_MT_N, false);
-                n_done++;
-            }
+        while (work) {  // uniform
+            const int k = __ffsll((long long)work) - 1;
+            work &= work - 1;
+            refill_ring(cfg, p, (first + k) >> 1, (first + k) & 1, (uint32_t)__shfl((int)flag, k, WAVE), lane, lds, lds + CTF_MT_N, false);
+            n_done++;
         }
         STEP_STAMP(4);
 #if STEP_TRACE
@@ -407,13 +485,7 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
 
     uint32_t left_ring = 0;
     if (live) group_step<METRICS, W>(R, cfg, p, (uint8_t*)(lds + g * SLW), e, j, g * W, flags, rw32, rw64, done_out, left_ring);
-    {   // which of the wave's envs left a ring of which stream: the next launch's tail blocks regenerate exactly those
-        const unsigned long long m_py = __ballot((left_ring & 1u) != 0), m_np = __ballot((left_ring & 2u) != 0);
-        if (lane == 0) {
-            unsigned long long* left = p.rng_left + ((size_t)parity * n_step_blocks + blockIdx.x) * 2;
-            left[0] = m_py; left[1] = m_np;
-        }
-    }
+    (void)left_ring;
     STEP_LDS_SYNC();
     STEP_STAMP(2);
 
@@ -1120,14 +1192,15 @@ extern "C" __global__ void __launch_bounds__(256) k_rng_refill(DevCfg cfg, DevPt
     uint32_t* dst = src + CTF_MT_N;
     const int first = (blockIdx.x * 4 + wave) * RNG_PAIRS_PER_WAVE;  // pair t = env e0 + t / 2, stream t % 2
     if (first >= 2 * count) return;
-    bool todo = false;
-    if (lane < RNG_PAIRS_PER_WAVE && first + lane < 2 * count) todo = init || !p.rngready[2 * (size_t)e0 + first + lane];
+    uint32_t flag = 1;
+    if (lane < RNG_PAIRS_PER_WAVE && first + lane < 2 * count) flag = init ? 0u : p.rngready[2 * (size_t)e0 + first + lane];
+    const bool todo = flag != 1u;
     unsigned long long work = __ballot(todo);
     while (work) {  // uniform
         const int k = __ffsll((long long)work) - 1;
         work &= work - 1;
         const int t = first + k, e = e0 + (t >> 1), stream = t & 1;
-        refill_ring(cfg, p, e, stream, lane, src, dst, init != 0);
+        refill_ring(cfg, p, e, stream, (uint32_t)__shfl((int)flag, k, WAVE), lane, src, dst, init != 0);
     }
 }
 
@@ -1164,18 +1237,21 @@ extern "C" __global__ void __launch_bounds__(256) k_export_rng(DevCfg cfg, DevPt
 extern "C" __global__ void k_get_counters(DevCfg cfg, DevPtrs p, unsigned long long* out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.n_envs) return;
-    for (int k = 0; k < 2; k++) out[2 * (size_t)e + k] = p.rngctr[4 * (size_t)e + k] + CTF_RP_POS(p.rngpos[2 * e + k]);
+    for (int k = 0; k < 2; k++) {
+        const uint32_t rp = p.rngpos[2 * e + k];
+        out[2 * (size_t)e + k] = p.rngctr[6 * (size_t)e + 2 * k + CTF_RP_CUR(rp)] + CTF_RP_POS(rp);
+    }
 }
 // ... and the way back (a checkpoint restore; followed by k_rng_refill(init)): ring 0 = the block that holds word n
 extern "C" __global__ void k_set_counters(DevCfg cfg, DevPtrs p, const unsigned long long* in) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.n_envs) return;
-    unsigned long long* ctr = p.rngctr + 4 * (size_t)e;
+    unsigned long long* ctr = p.rngctr + 6 * (size_t)e;
     for (int k = 0; k < 2; k++) {
         const unsigned long long n = in[2 * (size_t)e + k], blk = n / CTF_MT_N;
-        ctr[k] = blk * CTF_MT_N;
+        ctr[2 * k] = blk * CTF_MT_N;
         uint32_t* a = (k ? p.mt_np : p.mt_py) + (size_t)e * 2 * CTF_MT_N;
-        for (unsigned long long b = 0; b < CTF_MT_N / 4; b++) ctr_block(ctr[2 + k], blk * (CTF_MT_N / 4) + b, (uint32_t)k, a + 4 * b);
+        for (unsigned long long b = 0; b < CTF_MT_N / 4; b++) ctr_block(ctr[4 + k], blk * (CTF_MT_N / 4) + b, (uint32_t)k, a + 4 * b);
         p.rngpos[2 * e + k] = CTF_RP_MAKE((uint32_t)(n - blk * CTF_MT_N), 0);
     }
 }
@@ -1221,21 +1297,22 @@ extern "C" hipError_t ctf_launch_reset(const DevCfg& cfg, const DevPtrs& p, cons
 }
 template <bool METRICS, int W>
 static void launch_step_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done,
-                          uint32_t flags, uint32_t parity, hipStream_t st) {
+                          uint32_t flags, uint32_t phase, hipStream_t st) {
     constexpr int EPW = WAVE / W;
     const int nstep = (cfg.n_envs + EPW - 1) / EPW;
-    const dim3 grid(nstep * (cfg.rng_refill_every ? 1 + STEP_TAIL_K : 1)), block(WAVE);
+    const int ntail = cfg.rng_refill_every ? (2 * cfg.n_envs + STEP_TAIL_PAIRS - 1) / STEP_TAIL_PAIRS : 0;
+    const dim3 grid(nstep + ntail), block(WAVE);
     size_t sh = (size_t)EPW * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     if (sh < 2 * CTF_MT_N * 4) sh = 2 * CTF_MT_N * 4;  // a tail block stages two rings
-    hipLaunchKernelGGL((k_step<METRICS, W>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags, parity, nstep);
+    hipLaunchKernelGGL((k_step<METRICS, W>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags, phase, nstep);
 }
 template <bool METRICS>
 static void launch_step_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                          uint8_t* done, uint32_t flags, uint32_t parity, hipStream_t st) {
-    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
-    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
-    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
-    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, parity, st);
+                          uint8_t* done, uint32_t flags, uint32_t phase, hipStream_t st) {
+    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
+    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
+    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
+    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
 }
 // lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn
 static int step_lanes(const DevCfg& cfg) {
@@ -1244,12 +1321,12 @@ static int step_lanes(const DevCfg& cfg) {
     if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling knob (CTF_STEP_W), results are identical
     return w;
 }
-// parity: alternates from one step launch to the next (which half of p.rng_left this launch writes)
+// phase: counts the step launches (which share of a burst of stale rings this launch's tail blocks take)
 extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                                      uint8_t* done, uint32_t flags, uint32_t parity, hipStream_t st) {
+                                      uint8_t* done, uint32_t flags, uint32_t phase, hipStream_t st) {
     const int w = step_lanes(cfg);
-    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, parity, st);
-    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, parity, st);
+    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, phase, st);
+    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, phase, st);
     return hipGetLastError();
 }
 extern "C" int ctf_step_blocks(const DevCfg& cfg) { return (cfg.n_envs + WAVE / step_lanes(cfg) - 1) / (WAVE / step_lanes(cfg)); }

@@ -43,8 +43,9 @@
 #define CTF_NB_MIRROR 112
 #define CTF_P8_MIRROR 80
 // rngpos word of a stream: position 0..624 | current ring << 16.  Whether the OTHER ring is in place (regenerated and linked) is
-// a byte of its own, rngready: the consumer's launch writes the position, the regenerating wave — possibly of the same launch —
-// the flag.
+// a byte of its own, rngready: 1 = in place; 2 + r = ring r is stale (its consumer has moved on to ring 1 - r) and waits to be
+// regenerated; 0 = nothing valid yet (before the first k_rng_refill(init)).  The consumer's launch writes the position, the
+// regenerating wave — possibly of the same launch — the flag, and the flag alone says which ring is to be rebuilt from which.
 #define CTF_RP_POS(x) ((x) & 0xFFFFu)
 #define CTF_RP_CUR(x) (((x) >> 16) & 1u)
 #define CTF_RP_MAKE(pos, cur) ((uint32_t)(pos) | ((uint32_t)(cur) << 16))

@@ -28,34 +28,34 @@ DEFAULT_ARGS = dict(learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, gae=True,
                     clip_coef=0.2, clip_vloss=True, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, target_kl=None)
 
 
+def _reverse_scan(first, coeff, tail):
+    """x[t] = first[t] + coeff[t] * x[t + 1] for t = S-1 .. 0 with x[S] = tail: the one sequential pass of either estimator."""
+    out = torch.empty_like(first)
+    carry = tail
+    for t in range(first.shape[0] - 1, -1, -1):
+        carry = first[t] + coeff[t] * carry
+        out[t] = carry
+    return out
+
+
 def calculate_advantages(next_value, rewards, next_done, dones, values, gamma=0.99, gae_lambda=0.95, gae=True):
-    """ppo.py:145-170.  rewards / dones / values: [S, ...]; next_value / next_done: [...] -> (advantages, returns) [S, ...]."""
-    S = rewards.shape[0]
+    """The estimators of ppo.py:145-170 as one backward recurrence over whole-rollout tensors.
+    rewards / dones / values: [S, ...]; next_value / next_done: [...] -> (advantages, returns) [S, ...].
+
+    What follows a step — its value and whether the episode goes on — is the same tensor shifted by one step with the bootstrap
+    entry appended, so the TD residuals of all steps come out of one expression; the only sequential part is the discounted
+    reverse sum.  Every element goes through the reference's operations in the reference's order (tests/golden/learner_ref.npz
+    holds it to the last bits)."""
     with torch.no_grad():
-        next_value = next_value.reshape(rewards.shape[1:])
+        boot = next_value.reshape(rewards.shape[1:])
+        alive_after = 1.0 - torch.cat([dones[1:], next_done.reshape((1,) + tuple(rewards.shape[1:])).to(dones.dtype)], dim=0)
         if gae:
-            advantages = torch.zeros_like(rewards)
-            lastgaelam = 0
-            for t in reversed(range(S)):
-                if t == S - 1:
-                    nextnonterminal = 1.0 - next_done
-                    nextvalues = next_value
-                else:
-                    nextnonterminal = 1.0 - dones[t + 1]
-                    nextvalues = values[t + 1]
-                delta = rewards[t] + gamma * nextvalues * nextnonterminal - values[t]
-                advantages[t] = lastgaelam = delta + gamma * gae_lambda * nextnonterminal * lastgaelam
+            value_after = torch.cat([values[1:], boot.unsqueeze(0)], dim=0)
+            residual = rewards + gamma * value_after * alive_after - values
+            advantages = _reverse_scan(residual, gamma * gae_lambda * alive_after, torch.zeros_like(boot))
             returns = advantages + values
         else:
-            returns = torch.zeros_like(rewards)
-            for t in reversed(range(S)):
-                if t == S - 1:
-                    nextnonterminal = 1.0 - next_done
-                    next_return = next_value
-                else:
-                    nextnonterminal = 1.0 - dones[t + 1]
-                    next_return = returns[t + 1]
-                returns[t] = rewards[t] + gamma * nextnonterminal * next_return
+            returns = _reverse_scan(rewards, gamma * alive_after, boot)
             advantages = returns - values
     return advantages, returns
 

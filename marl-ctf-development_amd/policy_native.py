@@ -102,17 +102,29 @@ class CtfPolicyNative(CtfPolicy):
         self.grid_size, self.metadata_size, self.n_channels = grid_size, metadata_size, n_channels
         self._prep = None
         # Philox key of the action sampler and its running offset.  The key is unique per INSTANCE: a default-constructed
-        # module draws it from torch's generator (reproducible under torch.manual_seed, different for every module built),
-        # and a copy / unpickled module draws a new one (__setstate__) — two networks that share (key, offset) would sample
-        # from identical uniforms, i.e. perfectly correlated exploration of agent and opponent in self-play.
+        # module derives it from the state of torch's generator WITHOUT drawing from it (reproducible under torch.manual_seed,
+        # different for every module built, and no later torch draw moves because a module was built or copied), and a
+        # copy.deepcopy — how ppo.py-style loops make an opponent — gets a new one: two networks that share (key, offset) would
+        # sample from identical uniforms, i.e. perfectly correlated exploration of agent and opponent in self-play.  A pickle /
+        # torch.save round trip keeps (key, offset): a restored checkpoint resumes its action stream where it stopped.
         self._seed = self._fresh_key() if seed is None else int(seed) & (2 ** 64 - 1)
         self._calls = 0
         self._act_bufs = {}        # persistent activation matrices of act_from_codes, by (rows, row length, device)
         self.placement_probe_ms = None
 
     @staticmethod
-    def _fresh_key():
-        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    def _fresh_key(parent=None):
+        """A new module: a key that depends on where torch's CPU generator stands (read, not advanced) — building a module moves
+        it (weight init), so every module built gets its own, and the same torch.manual_seed gives the same keys.  A copy:
+        derived from its parent's key and the number of copies the parent has handed out."""
+        import hashlib
+
+        if parent is None:
+            material = torch.get_rng_state().numpy().tobytes()
+        else:
+            parent._n_copies = getattr(parent, "_n_copies", 0) + 1
+            material = parent._seed.to_bytes(8, "little") + parent._n_copies.to_bytes(8, "little")
+        return int.from_bytes(hashlib.blake2b(material, digest_size=8).digest(), "little") >> 2
 
     def reseed(self, seed):
         """Set the action sampler's Philox key explicitly (and restart its offset)."""
@@ -124,9 +136,23 @@ class CtfPolicyNative(CtfPolicy):
         d["_prep"], d["_act_bufs"] = None, {}
         return d
 
-    def __setstate__(self, state):  # copy.deepcopy / pickle: the copy samples from its own stream (see __init__)
-        super().__setstate__(state)
-        self._seed, self._calls = self._fresh_key(), 0
+    def __deepcopy__(self, memo):  # a COPY samples from its own stream (see __init__); a restored pickle keeps the original's
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__getstate__(), memo))
+        new._seed, new._calls, new._n_copies = self._fresh_key(parent=self), 0, 0
+        return new
+
+    def clone(self, reseed=True):
+        """A deep copy; ``reseed=False`` keeps the action sampler's (key, offset), e.g. to replay the original's draws."""
+        import copy
+
+        new = copy.deepcopy(self)
+        if not reseed:
+            new._seed, new._calls = self._seed, self._calls
+        return new
 
     # -- weights in the kernels' / the GEMM's layouts ----------------------------------------------
     def prepare(self):

@@ -37,8 +37,7 @@ struct hs_env {
     std::vector<uint16_t> vislog;
     std::vector<uint32_t> lds;
     int refill_every;
-    std::vector<uint8_t> left[2];  // per step parity: which rings each env left during that step (bit 0 random, bit 1 np.random)
-    int parity;
+    uint32_t phase;  // counts the steps (ctf_abi.hip: step_phase)
 };
 
 static void stream_of(hs_env* h, int e, int stream, StreamFull* st) { *st = stream_full(h->d, h->p, e, stream); }
@@ -48,20 +47,23 @@ static void refill_one(hs_env* h, int e, int stream) {
     StreamFull st;
     stream_of(h, e, stream, &st);
     if (st.ready) return;
+    st.cur = ring_source(h->p.rngready[2 * e + stream], h->p.rngpos[2 * e + stream]);
+    ring_counter_params(st.q, h->p, e, stream, st.cur);
     const uint32_t* src = st.r.raw + st.cur * CTF_MT_N;
     uint32_t* dst = st.r.raw + (1 - st.cur) * CTF_MT_N;
     ring_next_block<1>(0, src, dst, st.q, [] {});
     ring_digest<1>(0, dst, st.r, 1 - (int)st.cur, st.q);
     ring_link<1>(0, src, dst, st.r, (int)st.cur, st.q);
+    ring_counter_store(st.q, h->p, e, stream, 1u - st.cur);
     h->p.rngready[2 * e + stream] = 1;
 }
 // ... and what the import path does: the current ring's own digests first
 static void init_stream(hs_env* h, int e, int stream, uint32_t pos) {
-    h->left[0][e] &= (uint8_t)~(1u << stream); h->left[1][e] &= (uint8_t)~(1u << stream);
     h->p.rngpos[2 * e + stream] = CTF_RP_MAKE(pos, 0);
     h->p.rngready[2 * e + stream] = 0;
     StreamFull st;
     stream_of(h, e, stream, &st);
+    ring_counter_params(st.q, h->p, e, stream, 0);
     ring_digest<1>(0, st.r.raw, st.r, 0, st.q);
     refill_one(h, e, stream);
 }
@@ -83,7 +85,7 @@ static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64
         if (METRICS) memset(lds + GW + RW + AW + WW, 0, (size_t)((CTF_N_METRICS * N + 3) & ~3));
         uint32_t left_ring = 0;
         group_step<METRICS, 1>(R, d, h->p, (uint8_t*)lds, e, 0, 0, flags, rw32, rw64, done, left_ring);
-        h->left[h->parity][e] = (uint8_t)left_ring;
+        (void)left_ring;
         memcpy(h->grid.data() + (size_t)e * d.GS, lds, (size_t)d.GS);
         memcpy(h->rec.data() + (size_t)e * d.RS, lds + GW, (size_t)d.RS);
         if (METRICS) {
@@ -91,13 +93,13 @@ static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64
             for (int w = 0; w < CTF_N_METRICS * N; w++) h->metrics[(size_t)e * CTF_N_METRICS * N + w] += dl[w];
         }
     }
-    // the launch's TAIL blocks: the rings that were left during the PREVIOUS step are regenerated now — after this step's
-    // groups have run without them, which is the latest the real launch can get to them
+    // the launch's TAIL blocks: stale rings are regenerated, each env's in its share of the launches (k_step) — after this step's
+    // groups have run, which is the latest the real launch gets to them
     if (h->refill_every)
         for (int e = 0; e < d.n_envs; e++)
             for (int k = 0; k < 2; k++)
-                if (h->left[h->parity ^ 1][e] & (1u << k)) refill_one(h, e, k);
-    h->parity ^= 1;
+                if (h->p.rngready[2 * e + k] >= 2 && (uint32_t)(e + (int)h->phase) % (uint32_t)d.rng_spread == 0) refill_one(h, e, k);
+    h->phase++;
 }
 
 extern "C" {
@@ -122,9 +124,8 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
     h->rngpos.assign(E * 2, 0);
     h->rngready.assign(E * 2, 0);
     h->refill_every = h->d.rng_refill_every;
-    h->left[0].assign(E, 0); h->left[1].assign(E, 0);
-    h->parity = 0;
-    h->rngctr.assign(E * 4, 0);
+    h->phase = 0;
+    h->rngctr.assign(E * 6, 0);
     h->metrics.assign(E * CTF_N_METRICS * d.N, 0);
     h->vis.assign(E * d.N * d.GS, 0);
     h->vislog.assign((size_t)CTF_VIS_LOG * E * d.N, 0);
@@ -203,13 +204,16 @@ void hs_seed_counter(hs_env* h, int32_t e, uint64_t py_seed, uint64_t np_seed) {
     for (int k = 0; k < 2; k++) {
         uint32_t* a = (k ? h->p.mt_np : h->p.mt_py) + (size_t)e * 2 * CTF_MT_N;
         for (unsigned long long blk = 0; blk < CTF_MT_N / 4; blk++) ctr_block(seeds[k], blk, (uint32_t)k, a + 4 * blk);
-        h->p.rngctr[4 * e + k] = 0;
-        h->p.rngctr[4 * e + 2 + k] = seeds[k];
+        h->p.rngctr[6 * e + 2 * k] = 0;
+        h->p.rngctr[6 * e + 4 + k] = seeds[k];
         init_stream(h, e, k, 0);
     }
 }
 void hs_get_counters(hs_env* h, int32_t e, uint64_t* out) {
-    for (int k = 0; k < 2; k++) out[k] = h->p.rngctr[4 * e + k] + CTF_RP_POS(h->p.rngpos[2 * e + k]);
+    for (int k = 0; k < 2; k++) {
+        const uint32_t rp = h->p.rngpos[2 * e + k];
+        out[k] = h->p.rngctr[6 * e + 2 * k + CTF_RP_CUR(rp)] + CTF_RP_POS(rp);
+    }
 }
 
 void hs_reset(hs_env* h, int32_t e) {  // k_reset

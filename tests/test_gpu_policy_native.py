@@ -211,19 +211,27 @@ def test_decision_values_other_than_0_or_1_give_the_references_all_zero_mask():
 
 
 def test_every_policy_instance_samples_from_its_own_stream():
-    """Two default-constructed networks, and a deepcopy / pickle of one, must not share (Philox key, offset): identical
-    uniforms for agent and opponent would correlate their exploration perfectly in self-play."""
+    """Two default-constructed networks, and a deepcopy of one, must not share (Philox key, offset): identical uniforms for
+    agent and opponent would correlate their exploration perfectly in self-play.  A pickle round trip is a checkpoint: it keeps
+    (key, offset) and resumes the stream.  Making keys reads torch's generator but never draws from it."""
     import copy
     import pickle
 
     a = fill_(native.CtfPolicyNative(9, 14, 15, 22))
     b = fill_(native.CtfPolicyNative(9, 14, 15, 22))
+    before = torch.get_rng_state()
     c = copy.deepcopy(a)
-    d = pickle.loads(pickle.dumps(a))
-    assert len({a._seed, b._seed, c._seed, d._seed}) == 4
+    c2 = copy.deepcopy(a)
+    assert torch.equal(torch.get_rng_state(), before)  # copies do not advance torch's generator
+    assert len({a._seed, b._seed, c._seed, c2._seed}) == 4
+    assert a.clone(reseed=False)._seed == a._seed
     B = 8192
     y1 = torch.zeros((B, 256), dtype=torch.bfloat16, device="cuda")  # identical, flat logits for every sample
-    draws = [net.cuda()._head(y1)[0] for net in (a, b, c, d)]
+    a.cuda()._head(y1)  # the original has drawn once ...
+    d = pickle.loads(pickle.dumps(a))  # ... and its checkpoint resumes from there
+    assert (d._seed, d._calls) == (a._seed, a._calls) and a._calls > 0
+    assert torch.equal(d.cuda()._head(y1)[0], a._head(y1)[0])
+    draws = [net.cuda()._head(y1)[0] for net in (a, b, c, c2)]
     for i in range(4):
         for j in range(i + 1, 4):
             assert float((draws[i] == draws[j]).float().mean()) < 0.5  # independent draws agree ~1/9 of the time
