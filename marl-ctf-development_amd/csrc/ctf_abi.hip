@@ -16,7 +16,7 @@
 
 extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint64_t*, const uint64_t*, hipStream_t);
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
-extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint32_t, int, hipStream_t);
 extern "C" int ctf_step_blocks(const DevCfg&);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
@@ -285,7 +285,7 @@ extern "C" int ctf_reset(ctf_env* h, const uint8_t* mask_dev, void* stream) {
 extern "C" int ctf_step(ctf_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, 1, (hipStream_t)stream));
     return CTF_OK;
 }
 
@@ -313,7 +313,10 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
                                 uint16_t* meta, uint32_t reverse_mask, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, (hipStream_t)stream));
+    // (The ring regeneration rides at the tail of the step launch.  Running it as a launch of its own on a second stream, beside
+    // the render, was built and measured in round 3: the render lost more than the step kernel gained — 189-191 M against 198 M
+    // env-steps/s, profiles/r03_side_stream_ablation.md.)
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, 1, (hipStream_t)stream));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;

@@ -191,6 +191,11 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     memcpy(d->capture_pos, c->capture_pos, sizeof(d->capture_pos));
     memcpy(d->spawn_pos, c->spawn_pos, sizeof(d->spawn_pos));
     memcpy(d->start_pos, c->start_pos, sizeof(d->start_pos));
+    for (int t = 0; t < 2; t++) {
+        d->flag_pack |= ((uint32_t)(uint8_t)c->flag_pos[t][0] | ((uint32_t)(uint8_t)c->flag_pos[t][1] << 8)) << (16 * t);
+        d->capture_pack |= ((uint32_t)(uint8_t)c->capture_pos[t][0] | ((uint32_t)(uint8_t)c->capture_pos[t][1] << 8)) << (16 * t);
+        d->spawn_pack |= ((uint32_t)(uint8_t)c->spawn_pos[t][0] | ((uint32_t)(uint8_t)c->spawn_pos[t][1] << 8)) << (16 * t);
+    }
     for (int i = 0; i < N; i++) d->default_reverse |= (c->agent_team[i] == 1) ? (1 << i) : 0;
     for (int i = 0; i < N; i++) {
         d->team_mask |= (uint32_t)c->agent_team[i] << i;

@@ -59,6 +59,7 @@ struct DevCfg {
     uint32_t tag_th, tag_tl;
     int32_t np_pairs;               // rand() draws of one step without respawns: sum over the agents that deal damage of their opponents
     uint32_t dmg_mask;              // bit i = AGENT_TYPE_DAMAGE[type(i)] > 0
+    uint32_t flag_pack, capture_pack, spawn_pack;  // the two teams' cells: row 0 | col 0 << 8 | row 1 << 16 | col 1 << 24
     int32_t rng_mode;               // CTF_RNG_MT19937 / CTF_RNG_COUNTER
     // the tile render (k_observe_tiles): envs are taken in groups of tile_k, the smallest count whose blocks fill a whole
     // number (tile_tpg) of tiles; div_ob_tile divides a tile's byte offset inside its group (a multiple of the tile size) by obs_bytes

@@ -319,14 +319,15 @@ __device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p,
 // The per-agent loop of GridworldCtf.step is inherently sequential (later agents see earlier agents' moves, tags and
 // respawns), so parallelism is across envs — but one lane per env leaves one wave per SIMD and a kernel bound by the
 // dependent LDS / VALU chain.  Here the W lanes of a group run the env's control flow redundantly (state reads are LDS
-// broadcasts; state WRITES are done by sub-lane 0 only) and split the work that is parallel inside an agent's turn:
+// broadcasts; state writes are the same store from every lane) and split the work that is parallel inside an agent's turn:
 //   - tagging: every lane holds the rand() < TAG_PROBABILITY bits of its share of the step's np.random window and evaluates
 //     one opponent; __ballot finds the first hit, which is applied (possibly respawning, which consumes extra words) before
 //     the remaining opponents are re-evaluated from the shifted stream position — exactly the reference's draw order;
 //   - adjacency / zone metrics, healing, rewards, visitation: one agent per sub-lane;
-//   - the random words of the step (loads, tempering, threshold tests) and their replacement at the end.
+//   - the digests of the step's random words (ctf_mt.h) arrive with the staging loads; the MT19937 blocks themselves are
+//     regenerated by the launch's tail blocks.
 // 64 / W envs per wave means W times more waves (4 per SIMD for the arena) to hide the latency chain.
-// The logic itself — env_step, the two streams, group_step / group_finish — is ctf_step_core.h.
+// The logic itself — env_step, the two streams, group_step — is ctf_step_core.h.
 //
 #if STEP_TRACE
 #define STEP_STAMP(k) CTF_STAMP(k)
@@ -340,8 +341,35 @@ extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
 #define STEP_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-#define STEP_TAIL_PAIRS 16  // (env, stream) pairs a tail block of k_step looks after (ring regeneration)
+#define STEP_TAIL_PAIRS 16  // (env, stream) pairs a tail block looks after (ring regeneration)
 
+// A TAIL block of k_step: regenerates rings whose consumers have moved on (rngready says
+// which).  It looks after STEP_TAIL_PAIRS (env, stream) pairs; a stale ring of env e is taken by the launch with
+// (e + phase) % rng_spread == 0, because the envs' stream positions move in step (every env draws the same words per step, give
+// or take a respawn): most of them leave their block in the same step, and that burst is spread over rng_spread launches —
+// always before the ring is needed.  A tail block touches nothing a step block reads: an env whose ring is stale stands at the
+// head of its new block and looks at neither the other ring nor its mirror.
+__device__ __forceinline__ void tail_block(const DevCfg& cfg, const DevPtrs& p, int tb, uint32_t phase, int lane, uint32_t* lds) {
+    const int first = tb * STEP_TAIL_PAIRS;
+    uint32_t flag = 1;
+    if (lane < STEP_TAIL_PAIRS && first + lane < 2 * cfg.n_envs) flag = p.rngready[first + lane];
+    const int spread = cfg.rng_spread;
+    unsigned long long work = __ballot(flag >= 2u && (uint32_t)(((first + lane) >> 1) + (int)phase) % (uint32_t)spread == 0u);
+    STEP_STAMP(0);
+    int n_done = 0;
+    while (work) {  // uniform
+        const int k = __ffsll((long long)work) - 1;
+        work &= work - 1;
+        refill_ring(cfg, p, (first + k) >> 1, (first + k) & 1, (uint32_t)__shfl((int)flag, k, WAVE), lane, lds, lds + CTF_MT_N, false);
+        n_done++;
+    }
+    STEP_STAMP(4);
+#if STEP_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_step_trace[blockIdx.x][5] = (unsigned long long)n_done;
+#else
+    (void)n_done;
+#endif
+}
 // 16 blocks (= waves) per CU fit by LDS: the register budget is held to the matching 4 waves per SIMD (128 VGPRs)
 template <bool METRICS, int W>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -352,31 +380,8 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= n_step_blocks) {
-        // ---- a TAIL block: regenerates rings whose consumers have moved on (rngready says which).  It looks after STEP_TAIL_PAIRS
-        // (env, stream) pairs; a stale ring of env e is taken by the launch with (e + phase) % rng_spread == 0, because the envs'
-        // stream positions move in step (every env draws the same words per step, give or take a respawn): most of them leave
-        // their block in the same step, and that burst is spread over rng_spread launches — always before the ring is needed.
-        // Tail blocks start as step blocks retire (the LDS is full until then); they touch nothing a step block reads: an env
-        // whose ring is stale stands at the head of its new block and looks at neither the other ring nor its mirror.
-        const int first = ((int)blockIdx.x - n_step_blocks) * STEP_TAIL_PAIRS;
-        uint32_t flag = 1;
-        if (lane < STEP_TAIL_PAIRS && first + lane < 2 * cfg.n_envs) flag = p.rngready[first + lane];
-        const int spread = cfg.rng_spread;
-        unsigned long long work = __ballot(flag >= 2u && (uint32_t)(((first + lane) >> 1) + (int)phase) % (uint32_t)spread == 0u);
-        STEP_STAMP(0);
-        int n_done = 0;
-        while (work) {  // uniform
-            const int k = __ffsll((long long)work) - 1;
-            work &= work - 1;
-            refill_ring(cfg, p, (first + k) >> 1, (first + k) & 1, (uint32_t)__shfl((int)flag, k, WAVE), lane, lds, lds + CTF_MT_N, false);
-            n_done++;
-        }
-        STEP_STAMP(4);
-#if STEP_TRACE
-        if (threadIdx.x == 0 && blockIdx.x < 8192) g_step_trace[blockIdx.x][5] = (unsigned long long)n_done;
-#else
-        (void)n_done;
-#endif
+        // ---- a TAIL block (see tail_block): these start as step blocks retire — the LDS is full until then
+        tail_block(cfg, p, (int)blockIdx.x - n_step_blocks, phase, lane, lds);
         return;
     }
     STEP_STAMP(0);
@@ -1297,10 +1302,10 @@ extern "C" hipError_t ctf_launch_reset(const DevCfg& cfg, const DevPtrs& p, cons
 }
 template <bool METRICS, int W>
 static void launch_step_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done,
-                          uint32_t flags, uint32_t phase, hipStream_t st) {
+                          uint32_t flags, uint32_t phase, bool with_tail, hipStream_t st) {
     constexpr int EPW = WAVE / W;
     const int nstep = (cfg.n_envs + EPW - 1) / EPW;
-    const int ntail = cfg.rng_refill_every ? (2 * cfg.n_envs + STEP_TAIL_PAIRS - 1) / STEP_TAIL_PAIRS : 0;
+    const int ntail = with_tail ? (2 * cfg.n_envs + STEP_TAIL_PAIRS - 1) / STEP_TAIL_PAIRS : 0;
     const dim3 grid(nstep + ntail), block(WAVE);
     size_t sh = (size_t)EPW * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     if (sh < 2 * CTF_MT_N * 4) sh = 2 * CTF_MT_N * 4;  // a tail block stages two rings
@@ -1308,11 +1313,11 @@ static void launch_step_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* act
 }
 template <bool METRICS>
 static void launch_step_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                          uint8_t* done, uint32_t flags, uint32_t phase, hipStream_t st) {
-    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
-    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
-    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
-    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, phase, st);
+                          uint8_t* done, uint32_t flags, uint32_t phase, bool with_tail, hipStream_t st) {
+    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
+    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
+    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
+    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
 }
 // lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn
 static int step_lanes(const DevCfg& cfg) {
@@ -1321,12 +1326,14 @@ static int step_lanes(const DevCfg& cfg) {
     if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling knob (CTF_STEP_W), results are identical
     return w;
 }
-// phase: counts the step launches (which share of a burst of stale rings this launch's tail blocks take)
+// phase: counts the step launches (which share of a burst of stale rings this launch's tail blocks take); with_tail: the ring
+// regeneration rides at the tail of this launch
 extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                                      uint8_t* done, uint32_t flags, uint32_t phase, hipStream_t st) {
+                                      uint8_t* done, uint32_t flags, uint32_t phase, int with_tail, hipStream_t st) {
     const int w = step_lanes(cfg);
-    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, phase, st);
-    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, phase, st);
+    const bool tail = with_tail && cfg.rng_refill_every;
+    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, phase, tail, st);
+    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, phase, tail, st);
     return hipGetLastError();
 }
 extern "C" int ctf_step_blocks(const DevCfg& cfg) { return (cfg.n_envs + WAVE / step_lanes(cfg) - 1) / (WAVE / step_lanes(cfg)); }

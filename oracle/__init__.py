@@ -57,6 +57,8 @@ def lib():
         L.octf_philox_actions.argtypes = [P, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32]
         L.octf_run_batch.restype = C.c_uint64
         L.octf_run_batch.argtypes = [C.POINTER(CtfConfig), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]
+        L.octf_bench_digest.argtypes = [C.POINTER(CtfConfig), C.c_int32, P, C.c_uint32, C.c_int32, C.c_uint64, C.c_int32, C.c_uint64,
+                                        C.c_int32, P, P, P, P, P, P]
         _lib = L
     return _lib
 
@@ -142,3 +144,23 @@ def philox_actions(n_agents, seed, step, env_index):
 
 def run_batch(cfg, n_envs, n_steps, seed_base=0, action_seed=0, with_observe=True, n_threads=1):
     return lib().octf_run_batch(C.byref(cfg), n_envs, n_steps, int(seed_base), int(action_seed), int(with_observe), int(n_threads))
+
+
+DIGEST_MULT = 0x9E3779B97F4A7C15
+
+
+def digest_weights(n):
+    """w(i) = (i + 1) * DIGEST_MULT mod 2**64 as uint64: a digest is sum(value_i * w(i)) mod 2**64 (octf_bench_digest)."""
+    return (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(DIGEST_MULT)).astype(np.uint64)
+
+
+def bench_digest(cfg, seeds, env_offset, period, stagger_seed, n_steps, action_seed, n_threads):
+    """bench.py's protocol on the CPU for every env -> dict of per-step / per-env digests (see ctf_oracle.c)."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    E = int(seeds.shape[0])
+    out = dict(obs=np.zeros((n_steps, E), np.uint64), meta=np.zeros((n_steps, E), np.uint64), rew=np.zeros((n_steps, E), np.uint64),
+               done=np.zeros((n_steps, E), np.uint8), rng=np.zeros((E, 2), np.uint64), misc=np.zeros((E, 3), np.int32))
+    lib().octf_bench_digest(C.byref(cfg), E, _ptr(seeds), int(env_offset), int(period), int(stagger_seed), int(n_steps), int(action_seed),
+                            int(n_threads), _ptr(out["obs"]), _ptr(out["meta"]), _ptr(out["rew"]), _ptr(out["done"]), _ptr(out["rng"]),
+                            _ptr(out["misc"]))
+    return out

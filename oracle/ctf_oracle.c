@@ -634,3 +634,72 @@ uint64_t octf_run_batch(const ctf_config* cfg, int32_t n_envs, int32_t n_steps, 
     }
     return total;
 }
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* bench.py's protocol on the CPU, every env, reduced to digests (tests/test_gpu_parity.py)     */
+/* ------------------------------------------------------------------------------------------ */
+/* weight of element i of a digest: sum of value_i * w(i) modulo 2^64 (what torch's wrapping int64 arithmetic gives too) */
+static uint64_t digest_w(uint64_t i) { return (i + 1u) * 0x9E3779B97F4A7C15ull; }
+
+/*
+ * For each env e < n_envs (seeded seeds[e] for both generators, actions = the Philox stream of global env index env_offset + e):
+ *   1. bench.stagger_phases: `period` steps with action seed stagger_seed and auto-reset, a reset() of env e after step s
+ *      when e % period == s;
+ *   2. n_steps more steps with action seed action_seed and auto-reset; after each of them the digests of that env's float64
+ *      rewards (their bit patterns), observation block, metadata rows (f16 bits) and its done flag.
+ * At the end: the digests of both generators' states (624 words + position), env_step_count, the two capture counters.
+ * out arrays: obs_d / meta_d / rew_d u64 [n_steps][n_envs], done u8 [n_steps][n_envs], rng_d u64 [n_envs][2], misc i32 [n_envs][3].
+ */
+void octf_bench_digest(const ctf_config* cfg, int32_t n_envs, const uint64_t* seeds, uint32_t env_offset, int32_t period,
+                       uint64_t stagger_seed, int32_t n_steps, uint64_t action_seed, int32_t n_threads, uint64_t* obs_d,
+                       uint64_t* meta_d, uint64_t* rew_d, uint8_t* done_out, uint64_t* rng_d, int32_t* misc) {
+    const size_t obs_bytes = (size_t)cfg->n_agents * cfg->n_channels * cfg->grid_size * cfg->grid_size;
+    const size_t meta_elems = (size_t)cfg->n_agents * (2 * cfg->n_agents + 6);
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 16)
+    for (int32_t ei = 0; ei < n_envs; ei++) {
+        octf_env* e = octf_create(cfg);
+        uint8_t* obs = (uint8_t*)malloc(obs_bytes);
+        uint16_t* meta = (uint16_t*)malloc(meta_elems * 2);
+        int8_t actions[CTF_MAX_AGENTS];
+        double rewards[CTF_MAX_AGENTS];
+        uint8_t done;
+        octf_seed(e, seeds[ei], seeds[ei]);
+        for (int32_t s = 0; s < period; s++) {
+            octf_philox_actions(actions, cfg->n_agents, stagger_seed, (uint32_t)s, env_offset + (uint32_t)ei);
+            if (e->done) octf_reset(e);
+            octf_step(e, actions, rewards, &done);
+            if (ei % period == s) octf_reset(e);
+        }
+        for (int32_t t = 0; t < n_steps; t++) {
+            octf_philox_actions(actions, cfg->n_agents, action_seed, (uint32_t)t, env_offset + (uint32_t)ei);
+            if (e->done) octf_reset(e);
+            octf_step(e, actions, rewards, &done);
+            octf_observe(e, obs, meta, CTF_REVERSE_DEFAULT);
+            uint64_t a = 0, b = 0, c = 0;
+            for (size_t i = 0; i < obs_bytes; i++) a += obs[i] ? digest_w(i) * obs[i] : 0;
+            for (size_t i = 0; i < meta_elems; i++) b += (uint64_t)meta[i] * digest_w(i);
+            for (int i = 0; i < cfg->n_agents; i++) {
+                uint64_t bits;
+                memcpy(&bits, &rewards[i], 8);
+                c += bits * digest_w((uint64_t)i);
+            }
+            obs_d[(size_t)t * n_envs + ei] = a;
+            meta_d[(size_t)t * n_envs + ei] = b;
+            rew_d[(size_t)t * n_envs + ei] = c;
+            done_out[(size_t)t * n_envs + ei] = done;
+        }
+        uint32_t py[CTF_MT_N + 1], np_[CTF_MT_N + 1];
+        octf_get_rng_state(e, py, np_);
+        uint64_t r0 = 0, r1 = 0;
+        for (int i = 0; i <= CTF_MT_N; i++) { r0 += (uint64_t)py[i] * digest_w((uint64_t)i); r1 += (uint64_t)np_[i] * digest_w((uint64_t)i); }
+        rng_d[2 * (size_t)ei] = r0;
+        rng_d[2 * (size_t)ei + 1] = r1;
+        misc[3 * (size_t)ei] = e->step_count;
+        misc[3 * (size_t)ei + 1] = e->team_captures[0];
+        misc[3 * (size_t)ei + 2] = e->team_captures[1];
+        free(obs); free(meta);
+        octf_destroy(e);
+    }
+}

@@ -50,6 +50,12 @@ void octf_philox_actions(int8_t* actions, int32_t n_agents, uint64_t seed, uint3
 uint64_t octf_run_batch(const ctf_config* cfg, int32_t n_envs, int32_t n_steps, uint64_t seed_base,
                         uint64_t action_seed, int32_t with_observe, int32_t n_threads);
 
+/* bench.py's protocol (staggered episode phases, then n_steps of step()+observe()) for EVERY env, reduced to per-env, per-step
+ * digests: see ctf_oracle.c */
+void octf_bench_digest(const ctf_config* cfg, int32_t n_envs, const uint64_t* seeds, uint32_t env_offset, int32_t period,
+                       uint64_t stagger_seed, int32_t n_steps, uint64_t action_seed, int32_t n_threads, uint64_t* obs_d,
+                       uint64_t* meta_d, uint64_t* rew_d, uint8_t* done_out, uint64_t* rng_d, int32_t* misc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,6 +335,62 @@ def test_full_size_arena_properties_and_sample():
     vec.close()
 
 
+def _digest_rows(t2d, w, mask=None, chunk=2048):
+    """sum(value_i * w(i)) mod 2**64 of every row of an integer tensor [E, K] (oracle.digest_weights), in wrapping int64"""
+    out = torch.empty(t2d.shape[0], dtype=torch.int64, device=t2d.device)
+    for lo in range(0, t2d.shape[0], chunk):
+        v = t2d[lo:lo + chunk].to(torch.int64)
+        if mask is not None:
+            v = v & mask
+        out[lo:lo + chunk] = (v * w).sum(1)
+    return out
+
+
+@pytest.mark.parametrize("workload", ["arena", "arena20"])
+def test_every_env_of_the_benchs_state_matches_the_oracle(workload):
+    """What bench.py times, checked on ALL 65 536 envs: its own protocol (bench.stagger_phases: a discarded first episode, masked
+    resets that leave the envs at staggered episode phases, ~131 envs auto-reset per step) and then 32 step_observe(auto_reset)
+    steps, against the OpenMP oracle running the same protocol env by env (oracle.bench_digest).  Compared per env and per
+    step: the float64 rewards' bit patterns, done, the whole observation block and the metadata rows (as 64-bit weighted
+    sums), and at the end both MT19937 states, env_step_count and the capture counters.  The render runs through
+    ctf_step_observe, i.e. with the ring regeneration on the side stream beside it."""
+    import bench
+
+    E, steps, period = 65536, 32, 500
+    kw = _workload(workload)
+    seeds = pkg.sharding.env_seeds(1, 0, E)
+    vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=True, tune_placement=False, **kw)
+    cfg, _ = cfgmod.build_config(kw, log_metrics=True)
+    import os, time
+
+    t0 = time.perf_counter()
+    want = oracle.bench_digest(cfg, seeds, 0, period, 0x5747, steps, 0xC7F, min(len(os.sched_getaffinity(0)), 16))
+    t_cpu = time.perf_counter() - t0
+    vec.observe()
+    bench.stagger_phases(vec, torch, 0, period)
+    N, dev = vec.N_AGENTS, vec.device
+    wt = lambda n: torch.from_numpy(oracle.digest_weights(n).view(np.int64)).to(dev)
+    w_obs, w_meta, w_rew, w_rng = wt(vec.obs[0].numel()), wt(N * vec.META_LEN), wt(N), wt(625)
+    acts = torch.empty((E, N), dtype=torch.int8, device=dev)
+    i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    for t in range(steps):
+        vec.random_actions(acts, seed=0xC7F, step=t, env_offset=0)
+        rewards, done, obs, meta = vec.step_observe(acts, auto_reset=True, want_f64=True)
+        bad = (_digest_rows(obs.view(E, -1), w_obs) != i64(want["obs"][t])).nonzero()
+        assert bad.numel() == 0, f"{workload} step {t}: observation of envs {bad[:8].flatten().tolist()} ({bad.numel()} in all)"
+        assert torch.equal(_digest_rows(meta.view(torch.int16).view(E, -1), w_meta, mask=0xFFFF), i64(want["meta"][t])), f"{workload} step {t}: metadata"
+        assert torch.equal(_digest_rows(vec.rewards64.view(torch.int64), w_rew), i64(want["rew"][t])), f"{workload} step {t}: rewards"
+        assert torch.equal(done.cpu(), torch.from_numpy(want["done"][t])), f"{workload} step {t}: done"
+    py, npw = vec.get_rng_states()
+    assert torch.equal(_digest_rows(py, w_rng, mask=0xFFFFFFFF), i64(want["rng"][:, 0])), "random states"
+    assert torch.equal(_digest_rows(npw, w_rng, mask=0xFFFFFFFF), i64(want["rng"][:, 1])), "np.random states"
+    _, caps, nsteps = vec.counters()
+    assert np.array_equal(nsteps.cpu().numpy(), want["misc"][:, 0]) and np.array_equal(caps.cpu().numpy(), want["misc"][:, 1:])
+    assert vec.status() == 0
+    print(f"\n{workload}: all {E} envs x {steps} steps equal the oracle; oracle {t_cpu:.1f} s on the host cores")
+    vec.close()
+
+
 def _workload(name):
     if name == "arena20":
         return dict(pkg.configs.ARENA20_KWARGS, SCENARIO=pkg.configs.arena20_scenario())
