@@ -7,8 +7,9 @@
 
 One "step" = one pass of the hot path over one batch: GridworldCtf.step() for every env of the shard
 plus the N observations + metadata rows a rollout consumes (reference ppo.py:59-98), with auto-reset at
-episode end — the two launches of ctf_step_observe (issued here as ctf_step + ctf_observe so that a HIP event
-can sit between them).  Workload at N=1: BASELINE.json configs[2] — 8_arena
+episode end — the two launches of ctf_step_observe (k_step, whose tail blocks regenerate the MT19937 blocks the
+envs have used up, then the render).  About six of the timed steps issue them as ctf_step + ctf_observe instead, so
+that a HIP event can sit between the two for the per-kernel durations.  Workload at N=1: BASELINE.json configs[2] — 8_arena
 (arena_iii, 4v4, the reference's 15x15 map), 65 536 envs resident in HBM; N>1 keeps 65 536 envs per GPU
 (weak scaling), envs sharded by global index with no data-path collective (--rollout-exchange adds an
 asynchronous RCCL all-gather of the compact rollout tensors once per 16-step chunk, what a centralised
@@ -129,7 +130,7 @@ def stagger_phases(vec, torch, lo, period=500):
 
 
 def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_metrics=True, stagger=True, gather=None, dist=None,
-                 extras=True):
+                 extras=True, rng_mode="mt19937"):
     """-> dict of this rank's measurements of one workload (timed region = K calls of step_observe)."""
     sh = pkg.sharding
     label, make_kwargs = WORKLOADS[name]
@@ -137,7 +138,7 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     device = torch.device("cuda", local_rank)
     lo = rank * E
     seeds = sh.env_seeds(run, lo, lo + E)
-    vec = pkg.VecGridworldCtf(E, device=local_rank, py_seeds=seeds, np_seeds=seeds, log_metrics=log_metrics, **kwargs)
+    vec = pkg.VecGridworldCtf(E, device=local_rank, py_seeds=seeds, np_seeds=seeds, log_metrics=log_metrics, rng_mode=rng_mode, **kwargs)
     N, G, C = vec.N_AGENTS, vec.GRID_SIZE, vec.N_CHANNELS
     actions = torch.empty((W + K, E, N), dtype=torch.int8, device=device)
     for t in range(W + K):
@@ -145,9 +146,7 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     vec.observe()  # allocates (and places) the observation buffer
     if stagger:
         stagger_phases(vec, torch, lo, kwargs["GAME_STEPS"])
-    obs_bytes = N * C * G * G   # ctf_launch_observe's rule: one-shot 8 KiB tiles whenever an env's block allows them
-    tiles = obs_bytes % 16 == 0 and obs_bytes >= 8192 and os.environ.get("CTF_OBS_TILES", "1") != "0"
-    observe_kernel = "k_observe_tiles" if tiles else "k_observe"
+    observe_kernel = vec.observe_kernel()  # the library's own answer for this buffer (ctf_observe_kernel)
 
     def one_step(t, events=None):
         if gather is not None:
@@ -193,7 +192,8 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
                k_step_ms=float(step_all.mean()), k_observe_ms=float(obs_all.mean()),
                k_step_p=[float(x) for x in np.percentile(step_all, [10, 50, 90])],
                k_observe_p=[float(x) for x in np.percentile(obs_all, [10, 50, 90])],
-               kernel_timing_samples=len(ev), placement_probe_ms=vec.placement_probe_ms, placement_fill_ms=vec.placement_fill_ms, kwargs=kwargs)
+               kernel_timing_samples=len(ev), placement_probe_ms=vec.placement_probe_ms, placement_fill_ms=vec.placement_fill_ms,
+               placement=vec.placement, kwargs=kwargs)
     if extras:
         # outside the timed region: the same env-step with the observation in compact form (ctf_observe_codes: one byte per
         # cell instead of C one-hot bytes — what the GPU policy path consumes)
@@ -289,11 +289,9 @@ def main():
                      stagger=not args.no_stagger, gather=gather, dist=dist, extras=(rank == 0))
     my_ms = r["elapsed"] / K * 1e3
     elapsed = sh.max_over_ranks(r["elapsed"], device, world if not use_dist else max(world, 2))
-    ranks_seen, per_rank_ms = [rank], [my_ms]
-    if use_dist:
-        got = [None] * dist.get_world_size()
-        dist.all_gather_object(got, (rank, my_ms))
-        ranks_seen, per_rank_ms = [g[0] for g in got], [g[1] for g in got]
+    ranks_seen, per_rank_ms = sh.gather_rank_times(rank, my_ms, world if use_dist else 1)
+    # a multi-GPU line must verify itself: every rank of the job reported a time, exactly once
+    ranks_ok = sh.ranks_complete(ranks_seen, per_rank_ms, n_gpus)
 
     if rank == 0:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -331,9 +329,13 @@ def main():
             "kernel_timing_samples": r["kernel_timing_samples"],
             "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (r["k_step_ms"] * 1e-3) / 1e9,
             "episode_phase_spread": r.get("episode_phase_spread"),
+            # where the observation buffer landed: a box whose allocations are all of the slow kind explains its
+            # own lower number here — kind, the render's time over a plain fill of the same buffer, the slowest candidate seen
+            "placement": r["placement"],
             "placement_probe_ms": r["placement_probe_ms"],
             "placement_fill_ms": r["placement_fill_ms"],
             "device_status_bits": r["status"],
+            "ranks_ok": ranks_ok,
             "ranks_seen": sorted(ranks_seen),
             "per_rank_ms_per_step": [per_rank_ms[ranks_seen.index(k)] for k in sorted(ranks_seen)],
             "compact_observation": {"env_steps_per_s_per_gpu": r.get("compact_rate"), "obs_bytes_per_env": N * G * G + N * (2 * N + 6) * 2,
@@ -351,8 +353,18 @@ def main():
                     "roofline": roofline_of(r2, traffic_table),
                     "whole_step_hbm_frac": env_step_algorithmic_bytes(r2["N"], r2["C"], r2["G"]) * v2 / 1e9 / HBM_PEAK_GBS,
                     "kernels_ms": {"k_step": r2["k_step_ms"], r2["observe_kernel"]: r2["k_observe_ms"]},
-                    "placement_probe_ms": r2["placement_probe_ms"], "device_status_bits": r2["status"],
+                    "placement": r2["placement"], "placement_probe_ms": r2["placement_probe_ms"], "device_status_bits": r2["status"],
                 }
+            # SURVEY 8(a)'s opt-in counter-based RNG (ctf_env.h CTF_RNG_COUNTER): the same workload with Philox streams in place of
+            # the reference's two MT19937 generators — a secondary, never the headline (its trajectories are not the reference's)
+            rc = run_workload(pkg, torch, "arena", E, max(20, min(K, 100)), W, 0, local_rank, 1, args.run, log_metrics=not args.no_metrics,
+                              stagger=not args.no_stagger, extras=False, rng_mode="counter")
+            sec["arena_65536_counter_rng"] = {
+                "workload": f"{rc['label']}, {E} envs, rng_mode=counter (Philox4x32-10 streams; parity: the oracle reading the same tape)",
+                "value": E * rc["K"] / rc["elapsed"], "unit": "env-steps/s", "steps": rc["K"], "ms_per_step": rc["elapsed"] / rc["K"] * 1e3,
+                "kernels_ms": {"k_step": rc["k_step_ms"], rc["observe_kernel"]: rc["k_observe_ms"]}, "placement": rc["placement"],
+                "device_status_bits": rc["status"],
+            }
             try:  # BASELINE configs[4] on one GPU: self-play rollout (env + two policy networks) + the reference's PPO update
                 import bench_rollout
 
@@ -366,6 +378,8 @@ def main():
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
+    if not ranks_ok:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: ranks seen {sorted(ranks_seen)} with times {per_rank_ms} — not every rank of the job reported")
 
 
 if __name__ == "__main__":

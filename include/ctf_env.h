@@ -197,6 +197,9 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way. */
 #define CTF_REVERSE_DEFAULT 0xFFFFFFFFu
 int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t reverse_mask, void* stream);
+/* which of the two a ctf_observe into obs_dev launches: 1 = k_observe_tiles, 0 = k_observe (profiling: attributing a measured
+ * duration to the right kernel) */
+int32_t ctf_observe_kernel(const ctf_env* env, const uint8_t* obs_dev);
 
 /* The same observation in compact form: the tile planes 1..C-1 of standardise_state are one-hot per cell
  * (plane k+1 = (relabelled grid == TILES_USED[k]), gridworld_ctf.py:990-1001) and plane 0 holds the single

@@ -18,6 +18,7 @@ extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint6
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
 extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint32_t, int, hipStream_t);
 extern "C" int ctf_step_blocks(const DevCfg&);
+extern "C" int ctf_observe_uses_tiles(const DevCfg&, const uint8_t*);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_random_actions(const DevCfg&, int8_t*, uint64_t, uint32_t, uint32_t, hipStream_t);
@@ -108,6 +109,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->d.n_cus = d.n_cus = h->n_cus;
     const size_t E = (size_t)n_envs;
     const size_t vis_elems = d.log_metrics ? E * d.N * d.GS : 1, met_elems = d.log_metrics ? E * CTF_N_METRICS * d.N : 1;
 #define ALLOC(ptr, bytes)                                                                                      \
@@ -299,6 +301,11 @@ extern "C" int ctf_observe(ctf_env* h, uint8_t* obs, uint16_t* meta, uint32_t re
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;
+}
+
+extern "C" int32_t ctf_observe_kernel(const ctf_env* h, const uint8_t* obs) {
+    if (!h) return -1;
+    return ctf_observe_uses_tiles(h->d, obs) ? 1 : 0;
 }
 
 extern "C" int ctf_observe_codes(ctf_env* h, uint8_t* codes, uint16_t* meta, uint16_t* selfcells, uint32_t reverse_mask, void* stream) {

@@ -108,6 +108,7 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     for (int k = 0; k < G * G; k++)
         if (c->init_grid[k] > 13) return fail(CTF_E_INVALID, "init_grid[%d] = %d", k, c->init_grid[k]);
 
+    d->n_cus = 256;  // (ctf_create overwrites it with the device's count)
     d->n_envs = n_envs; d->N = N; d->G = G; d->GG = G * G; d->C = C; d->M = 2 * N + 6;
     d->game_steps = c->game_steps; d->flip_axis = c->flip_axis;
     d->home_flag_capture = c->home_flag_capture; d->use_adjusted = c->use_adjusted_rewards;
@@ -170,10 +171,6 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
             const int v = atoi(ov);
             if (v >= 1 && v <= d->rng_spread) d->rng_spread = v;
         }
-    }
-    if (const char* ov = getenv("CTF_STEP_STAGGER")) {  // profiling knob: 10 ns ticks between the cohorts of k_step
-        const int v = atoi(ov);
-        if (v >= 0 && v <= 100000) d->step_stagger = v;
     }
     if (const char* ov = getenv("CTF_STEP_W")) {
         const int w = atoi(ov);

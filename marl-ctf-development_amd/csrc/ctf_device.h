@@ -54,7 +54,7 @@ struct DevCfg {
     int32_t rng_safe_ahead;         // words: a step that starts this far (or further) before the end of its block needs no other ring
     int32_t rng_spread;             // a stale ring is regenerated within this many launches: a burst of them (the envs' positions
                                     // move in step) is spread over as many launches
-    int32_t step_stagger;           // start offset between the four cohorts of k_step's blocks, in 10 ns ticks (0 = none)
+    int32_t n_cus;                  // compute units of the device (launch shapes)
     // np.random.rand() < TAG_PROBABILITY on the 53-bit integer x = (a >> 5) * 2^26 + (b >> 6): x < tag_thr, split at bit 26
     uint32_t tag_th, tag_tl;
     int32_t np_pairs;               // rand() draws of one step without respawns: sum over the agents that deal damage of their opponents

@@ -341,7 +341,9 @@ extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
 #define STEP_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+#ifndef STEP_TAIL_PAIRS
 #define STEP_TAIL_PAIRS 16  // (env, stream) pairs a tail block looks after (ring regeneration)
+#endif
 
 // A TAIL block of k_step: regenerates rings whose consumers have moved on (rngready says
 // which).  It looks after STEP_TAIL_PAIRS (env, stream) pairs; a stale ring of env e is taken by the launch with
@@ -390,14 +392,6 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
         g_step_trace[blockIdx.x][39] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
                                        ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
 #endif
-    // Every block of the launch is resident at once, so without this all waves would load, compute and store in step: the
-    // memory system idles while they compute and is swamped at both ends.  The four quarters of the grid start a quarter of
-    // `step_stagger` apart instead (sleeping costs no issue slots): one cohort's loads / stores run under the others' turns.
-    if (cfg.step_stagger) {
-        const unsigned long long t0 = wall_clock64();
-        const unsigned long long wait = (unsigned long long)((4u * blockIdx.x) / gridDim.x) * (unsigned long long)cfg.step_stagger;
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
     const int g = lane / W, j = lane % W;
     const int env0 = blockIdx.x * EPW;
     const int nvalid = min(EPW, cfg.n_envs - env0);
@@ -1319,11 +1313,14 @@ static void launch_step_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8
     else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
     else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
 }
-// lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn
+// lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn — and more
+// (up to 8) for a batch too small to give every SIMD of the chip a wave: fewer envs per wave then, i.e. a shorter divergent
+// chain per wave (0_the_split at 4 096 envs: 2 -> 8 lanes, 0.0312 -> 0.0280 ms per env-step).  Results do not depend on it.
 static int step_lanes(const DevCfg& cfg) {
     const int mo = cfg.n_opp[0] > cfg.n_opp[1] ? cfg.n_opp[0] : cfg.n_opp[1];
     int w = mo <= 1 ? 1 : (mo <= 2 ? 2 : (mo <= 4 ? 4 : 8));
-    if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling knob (CTF_STEP_W), results are identical
+    while (w < 8 && (long long)cfg.n_envs * w / WAVE < 2LL * cfg.n_cus) w *= 2;
+    if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling / test knob (CTF_STEP_W)
     return w;
 }
 // phase: counts the step launches (which share of a burst of stale rings this launch's tail blocks take); with_tail: the ring
@@ -1353,12 +1350,19 @@ static int obs_reserve_blocks() {
     static const int v = [] { const char* e = getenv("CTF_OBS_RESERVE_BLOCKS"); return e ? atoi(e) : 0; }();
     return v < 0 ? 0 : v;
 }
+static int observe_align(const DevCfg& cfg, const uint8_t* obs) {
+    const uintptr_t a = (uintptr_t)obs;
+    return ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0) ? 16 : (((cfg.obs_bytes % 4) == 0 && (a % 4) == 0) ? 4 : 1);
+}
+// the one rule by which a render into `obs` is the tile kernel (1) or the wave-per-env kernel (0)
+extern "C" int ctf_observe_uses_tiles(const DevCfg& cfg, const uint8_t* obs) {
+    const char* tenv = getenv("CTF_OBS_TILES");  // 0 / 1: never / whenever possible (tests, profiling)
+    return obs && observe_align(cfg, obs) == 16 && cfg.tile_k > 0 && (tenv ? atoi(tenv) != 0 : OBS_TILES_DEFAULT);
+}
 extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask,
                                          int n_cus, hipStream_t st) {
-    const uintptr_t a = (uintptr_t)obs;
-    const int align = ((cfg.obs_bytes % 16) == 0 && (a % 16) == 0) ? 16 : (((cfg.obs_bytes % 4) == 0 && (a % 4) == 0) ? 4 : 1);
-    const char* tenv = getenv("CTF_OBS_TILES");  // 0 / 1: never / whenever possible (tests, profiling)
-    const bool tiles = obs && align == 16 && cfg.tile_k > 0 && (tenv ? atoi(tenv) != 0 : OBS_TILES_DEFAULT);
+    const int align = observe_align(cfg, obs);
+    const bool tiles = ctf_observe_uses_tiles(cfg, obs) != 0;
     if (tiles) {
         // one wave per tile, 4 independent waves per block; tile_bx blocks per group of tile_k envs (whose blocks fill tile_tpg tiles)
         const int wpb = CTF_OBS_TILE_WPB;

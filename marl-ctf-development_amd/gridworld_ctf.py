@@ -64,7 +64,7 @@ class VecGridworldCtf:
     """
 
     def __init__(self, n_envs, device=None, py_seeds=None, np_seeds=None, log_metrics=True, tune_placement=None, _lib=None,
-                 rng_mode="mt19937", **env_kwargs):
+                 rng_mode="mt19937", placement_tries=None, placement_gib=None, **env_kwargs):
         """tune_placement: pick the observation buffer among a few candidate allocations by timing the render into each
         (default: on for batches whose observation block exceeds 256 MiB).  On MI355X about half of all large hipMalloc
         allocations stream 20 % slower than the others (6.5 vs 5.3 TB/s for a bare store stream into the very same
@@ -106,8 +106,13 @@ class VecGridworldCtf:
         if tune_placement is None:
             tune_placement = E * N * self.N_CHANNELS * self.GRID_SIZE ** 2 > (256 << 20)
         self._tune_placement = bool(tune_placement)
+        import os
+
+        self._placement_tries = int(placement_tries if placement_tries is not None else os.environ.get("CTF_PLACEMENT_TRIES", 8))
+        self._placement_gib = float(placement_gib if placement_gib is not None else os.environ.get("CTF_PLACEMENT_GIB", 16))
         self.placement_probe_ms = None
         self.placement_fill_ms = None
+        self.placement = None  # what the placement search found: kind fast / intermediate / slow, render / fill ratio, ...
 
     @property
     def obs(self):
@@ -130,16 +135,17 @@ class VecGridworldCtf:
                                          device=self.device)
         return self._codes
 
-    def _tune_obs_placement(self, tries=64, good_enough=1.06, memory_share=0.45):
+    def _tune_obs_placement(self, good_enough=1.06):
         """Keep the candidate allocation the render streams into fastest (see __init__); frees the others.
 
-        Up to ``tries`` candidates, all held until the end (a freed one would simply be handed out again), but never more
-        than ``memory_share`` of the device memory that is free at the start: on some boxes only one allocation in twelve to
-        twenty-five is of the fast kind (tools/alloc_probe7.hip, alloc_probe8.hip), and a probe costs about a millisecond.
+        BOUNDED: at most ``placement_tries`` candidates (default 8; ctor argument or CTF_PLACEMENT_TRIES) and never more than
+        ``placement_gib`` GiB of them at once (default 16; CTF_PLACEMENT_GIB) nor 45 % of the free device memory — a
+        co-resident policy / learner is not starved while this searches, and an allocation failure just ends the search.
+        All candidates are held until the end (a freed one would simply be handed out again).
 
         A candidate is good enough when the render into it takes at most ``good_enough`` x the time of a plain ``fill_`` of
         the same buffer (which does not depend on the buffer's kind): 1.04-1.07 for the best buffers seen, 1.08-1.12 for an
-        intermediate kind, 1.2-1.3 for the slow one; searching on costs milliseconds, the best one is kept."""
+        intermediate kind, 1.2-1.3 for the slow one.  ``self.placement`` says what was found."""
         torch = _torch()
         stream = torch.cuda.current_stream(self.device)
 
@@ -158,24 +164,34 @@ class VecGridworldCtf:
             return timed(lambda: self.observe(meta=False))
 
         best = self.obs
+        nbytes = max(1, best.numel())
         free_bytes, _ = torch.cuda.mem_get_info(self.device)
-        tries = max(1, min(int(tries), 1 + int(memory_share * free_bytes) // max(1, best.numel())))
-        fill_ms = timed(lambda: best.fill_(0))
+        budget = min(int(self._placement_gib * (1 << 30)), int(0.45 * free_bytes))
+        tries = max(1, min(int(self._placement_tries), 1 + budget // nbytes))
         best_ms, times = probe(best), []
         times.append(best_ms)
+        fill_ms = timed(lambda: best.fill_(0))
         candidates, cand = [best], None  # rejected candidates stay allocated until the end, so that new ones land elsewhere
         for _ in range(tries - 1):
             if best_ms <= good_enough * fill_ms:
                 break
-            cand = torch.empty_like(best)
+            try:
+                cand = torch.empty_like(best)
+            except torch.cuda.OutOfMemoryError:
+                break  # (fragmentation, another process on the GPU): the best one so far is kept
             candidates.append(cand)
             ms = probe(cand)
             times.append(ms)
             if ms < best_ms:
                 best, best_ms = cand, ms
         self.obs = best
+        fill_ms = timed(lambda: best.fill_(0))  # of the buffer that is kept
+        ratio = best_ms / fill_ms
         self.placement_probe_ms = times
         self.placement_fill_ms = fill_ms
+        self.placement = dict(kind="fast" if ratio <= 1.07 else ("intermediate" if ratio <= 1.14 else "slow"), render_over_fill=ratio,
+                              render_ms=best_ms, fill_ms=fill_ms, candidates=len(times), slowest_candidate_render_ms=max(times),
+                              searched_bytes=len(times) * nbytes)
         n_held = len(candidates)
         del candidates, cand
         if n_held > 4:
@@ -273,6 +289,10 @@ class VecGridworldCtf:
         _abi.check(self._lib.ctf_observe(self._h, C.c_void_p(self.obs.data_ptr()) if obs else None,
                                          C.c_void_p(self.meta.data_ptr()) if meta else None, rm, self._stream()), self._lib)
         return self.obs, self.meta
+
+    def observe_kernel(self):
+        """Which kernel ``observe`` launches for this object's buffer: "k_observe_tiles" or "k_observe" (the library's own rule)."""
+        return "k_observe_tiles" if self._lib.ctf_observe_kernel(self._h, C.c_void_p(self.obs.data_ptr())) == 1 else "k_observe"
 
     def observe_codes(self, reverse_mask=None, codes=True, meta=True):
         """The observation in compact form -> (codes uint8 [E, N, G, G], meta float16 [E, N, 2N+6]): low 7 bits = the tile

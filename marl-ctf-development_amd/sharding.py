@@ -236,6 +236,24 @@ class RolloutHandoff:
         return out
 
 
+def gather_rank_times(rank, my_ms, world):
+    """-> (ranks_seen, per_rank_ms): what every rank of the job reports for itself, all-gathered (every rank gets the lists)."""
+    if world == 1:
+        return [rank], [my_ms]
+    import torch.distributed as dist
+
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, (rank, my_ms))
+    return [g[0] for g in got], [g[1] for g in got]
+
+
+def ranks_complete(ranks_seen, per_rank_ms, n):
+    """True iff ranks 0..n-1 each reported exactly one positive time: a multi-GPU bench line verifies itself with this and
+    exits non-zero otherwise."""
+    return (sorted(ranks_seen) == list(range(n)) and len(per_rank_ms) == n
+            and all(t is not None and t == t and t > 0 for t in per_rank_ms))
+
+
 def max_over_ranks(value, device, world):
     """MAX over ranks of a python float (the timing rule of bench.py)."""
     if world == 1:

@@ -17,7 +17,7 @@ maps = importlib.import_module("marl-ctf-development_amd.maps").CtfScenarios
 
 def case_names():
     names = (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    return sorted(n for n in names if n != "maps_ref" and not n.startswith(("rollout_", "duel_", "policy_", "learner_")))
+    return sorted(n for n in names if n != "maps_ref" and not n.startswith(("rollout_", "duel_", "policy_", "learner_", "counter_")))
 
 
 def duel_case_names():

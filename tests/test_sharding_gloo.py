@@ -105,6 +105,11 @@ def _worker(rank, world, port, q):
             assert torch.equal(nd, all_ids % 2)
         slow = sh.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
         assert slow == float(world)
+        # bench.py's self-check of a multi-GPU line: every rank of the job reported one positive time
+        seen, times = sh.gather_rank_times(rank, 1.0 + rank, world)
+        assert sh.ranks_complete(seen, times, world) and sorted(seen) == list(range(world))
+        assert not sh.ranks_complete(seen[:-1], times[:-1], world) and not sh.ranks_complete(seen, [0.0] + times[1:], world)
+        assert not sh.ranks_complete([0] * world, times, world)
         q.put((rank, "ok"))
     except Exception as exc:  # pragma: no cover
         q.put((rank, repr(exc)))

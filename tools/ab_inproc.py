@@ -68,7 +68,7 @@ for t in range(64):
     vecs[0][1].random_actions(ACTS[t], seed=0xC7F, step=t)
 if not os.environ.get("AB_BENCHLIKE"):
     ACTS[:] = acts
-res = {f: ([], [], []) for f, _ in vecs}
+res = {f: ([], [], [], []) for f, _ in vecs}
 os.environ["CTF_FUSED"] = os.environ.get("AB_FUSED", "1")  # step_observe below: the single launch where the build has one
 for rnd in range(4):
     for flags, v in vecs:
@@ -89,11 +89,12 @@ for rnd in range(4):
             res[flags][0].append(np.median([a.elapsed_time(b) for a, b, c in ev]))
             res[flags][1].append(np.median([b.elapsed_time(c) for a, b, c in ev]))
             res[flags][2].append(np.median([a.elapsed_time(b) for a, b in ev2]))
+            res[flags][3].append(np.mean([a.elapsed_time(b) for a, b, c in ev]))  # the step launch's MEAN (its tail blocks come in bursts)
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
 for a, b in ev:
     a.record(); shared_obs.fill_(1); b.record()
 torch.cuda.synchronize()
 print("reference: torch fill_ of the same buffer %.4f ms" % np.median([a.elapsed_time(b) for a, b in ev]), flush=True)
-for flags, (st, ob, so) in res.items():
-    print(f"[{flags or 'default'}] step {np.mean(st):.4f} ms  observe {np.mean(ob):.4f} ms  step_observe {np.mean(so):.4f} ms  "
+for flags, (st, ob, so, sm) in res.items():
+    print(f"[{flags or 'default'}] step {np.mean(st):.4f} ms (mean of all launches {np.mean(sm):.4f})  observe {np.mean(ob):.4f} ms  step_observe {np.mean(so):.4f} ms  "
           f"(observe rounds: {', '.join('%.4f' % x for x in ob)})", flush=True)
