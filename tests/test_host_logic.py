@@ -144,10 +144,13 @@ def test_native_policy_module_copies_and_pickles_without_its_device_side_state()
     net = native.CtfPolicyNative(9, 14, 15, 22, seed=5)
     net._prep = {"lib": object(), "stamp": None}      # stands for the ctypes handle and device operands
     net._act_bufs = {(1, 2, 0): torch.zeros(1)}
-    for clone in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+    net._calls = 3
+    dup, restored = copy.deepcopy(net), pickle.loads(pickle.dumps(net))
+    for clone in (dup, restored):
         assert clone._prep is None and clone._act_bufs == {}
-        assert clone._seed != 5 and clone._calls == 0  # a copy samples from its own Philox stream (policy_native.__setstate__)
         assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), net.state_dict().values()))
+    assert dup._seed != 5 and dup._calls == 0                # a COPY samples from its own Philox stream (policy_native.__deepcopy__)
+    assert (restored._seed, restored._calls) == (5, 3)       # a restored checkpoint resumes the original's stream
 
 
 def test_the_synthetic_20x20_arena_of_bench_is_the_map_of_its_golden_trajectory():
