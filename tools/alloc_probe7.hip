@@ -19,7 +19,10 @@ __global__ void __launch_bounds__(256) k_fill(uint8_t* out, size_t bytes) {
         *(u32x4*)(o + (size_t)u * 1024 + (size_t)lane * 16) = v;
     }
 }
-static float probe(uint8_t* buf, size_t bytes) {
+// writes min(bytes, alloc_bytes) rounded down to whole groups of 8 blocks of four 8 KiB tiles: never past the allocation
+static float probe(uint8_t* buf, size_t alloc_bytes, size_t bytes) {
+    if (bytes > alloc_bytes) bytes = alloc_bytes;
+    bytes = bytes / (8 * 4 * 8192) * (8 * 4 * 8192);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     const int grid = (int)(bytes / 8192 / 4);
     float sum = 0;
@@ -40,7 +43,7 @@ int main(int argc, char** argv) {
         uint8_t* buf;
         if (hipMalloc(&buf, bytes) != hipSuccess) { printf("\nhipMalloc failed at %d\n", i); break; }
         keep.push_back(buf);
-        printf(" %.3f", probe(buf, bytes));
+        printf(" %.3f", probe(buf, bytes, bytes));
         if (i % 20 == 19) printf("\n");
         fflush(stdout);
     }
@@ -53,7 +56,7 @@ int main(int argc, char** argv) {
         uint8_t* buf;
         if (hipMalloc(&buf, bytes) != hipSuccess) break;
         keep.push_back(buf);
-        printf(" %.3f", probe(buf, bytes));
+        printf(" %.3f", probe(buf, bytes, bytes));
     }
     printf("\n");
     return 0;

@@ -22,7 +22,10 @@ __global__ void __launch_bounds__(256) k_fill(uint8_t* out, size_t bytes) {
         *(u32x4*)(o + (size_t)u * 1024 + (size_t)lane * 16) = v;
     }
 }
-static float probe(uint8_t* buf, size_t bytes) {
+// writes min(bytes, alloc_bytes) rounded down to whole groups of 8 blocks of four 8 KiB tiles: never past the allocation
+static float probe(uint8_t* buf, size_t alloc_bytes, size_t bytes) {
+    if (bytes > alloc_bytes) bytes = alloc_bytes;
+    bytes = bytes / (8 * 4 * 8192) * (8 * 4 * 8192);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     const int grid = (int)(bytes / 8192 / 4);  // bytes is a multiple of 8 * 4 * 8192
     float sum = 0;
@@ -60,7 +63,7 @@ int main() {
                 acc.location = prop.location;
                 acc.flags = hipMemAccessFlagsProtReadWrite;
                 CK(hipMemSetAccess(va, total, &acc, 1));
-                printf(" %.3f", probe((uint8_t*)va, probe_bytes));
+                printf(" %.3f", probe((uint8_t*)va, total, probe_bytes));
                 fflush(stdout);
                 CK(hipMemUnmap(va, total));
                 for (size_t i = 0; i < n; i++) CK(hipMemRelease(hs[i]));
