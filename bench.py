@@ -368,9 +368,9 @@ def main():
             try:  # BASELINE configs[4] on one GPU: self-play rollout (env + two policy networks) + the reference's PPO update
                 import bench_rollout
 
-                sec["ppo_selfplay_16384x16"] = bench_rollout.run(envs=16384, steps=16, device=local_rank)
+                sec["ppo_selfplay_65536x16"] = bench_rollout.run(envs=65536, steps=16, device=local_rank)
             except Exception as exc:  # a secondary must never cost the headline line
-                sec["ppo_selfplay_16384x16"] = {"error": repr(exc)}
+                sec["ppo_selfplay_65536x16"] = {"error": repr(exc)}
             line["secondary"] = sec
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, r["kwargs"])

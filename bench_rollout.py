@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update_epochs=4, num_minibatches=4, device=0):
+def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update_epochs=4, num_minibatches=4, device=0, micro_batch=262144):
     """-> dict: rollout / update / total env-steps per second of one PPO iteration (rollout of `steps` env steps of `envs`
     envs, then `update_epochs` x `num_minibatches` minibatch updates over its envs * steps * 4 samples)."""
     import torch
@@ -62,10 +62,11 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         import copy
 
         samples = envs * steps * (vec.N_AGENTS // 2)
-        micro = min(16384, samples // num_minibatches)
-        # MIOpen compiles its convolution kernels on first use of every (batch, C, H, W) shape (about a minute on a fresh
-        # box), and its solver for batches of 10^5 samples runs at 6 k samples/s: a minibatch is evaluated in pieces of 16 384
-        # (4.5 M samples/s; learner.optimise(micro_batch=): the same update), and the warm-up runs one such piece untimed
+        micro = min(micro_batch, samples // num_minibatches)
+        # A minibatch is evaluated in pieces (learner.optimise(micro_batch=): the same update, gradients accumulated).  MIOpen
+        # compiles its convolution kernels on first use of every (batch, C, H, W) shape (up to a minute on a fresh box), so the
+        # warm-up runs one such piece untimed.  Pieces of 262 144 samples: 8.0 M sample-passes/s against 4.5 / 6.9 M at 16 384 /
+        # 65 536 through the channels-last path of policy.CtfPolicy.trunk_codes (tools/learner_breakdown.py; 9 GB of activations)
         log(f"rollout {rollout_s:.3f} s; warm-up piece of {micro} samples (MIOpen compiles its kernels) ...")
         throwaway = learner.PPOLearner(copy.deepcopy(nets[0]), vec.N_CHANNELS, update_epochs=1, num_minibatches=1)
         adv, ret = throwaway.advantages(out)
@@ -86,8 +87,8 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
             "update_sample_passes_per_s": samples * update_epochs / update_s,
             "value": envs * steps / (rollout_s + update_s), "learner_share_of_time": update_s / (rollout_s + update_s),
             "losses_v_pg_entropy": [float(x) for x in losses],
-            "note": "the learner is the reference's stock-PyTorch PPO update on expanded one-hot minibatches (out of the accelerated "
-                    "path's scope); it dominates the iteration",
+            "note": "the learner is the reference's PPO update (ppo.py:174-242) in PyTorch on the compact rollout: one-hot planes by table "
+                    "lookup, channels-last bf16 convolutions (MIOpen), hipBLASLt GEMMs; it still dominates the iteration",
         })
     else:
         res["value"] = res["rollout_env_steps_per_s"]
@@ -105,8 +106,9 @@ def main():
     ap.add_argument("--no-update", action="store_true", help="rollout only (round 1's figure)")
     ap.add_argument("--update-epochs", type=int, default=4)
     ap.add_argument("--num-minibatches", type=int, default=4)
+    ap.add_argument("--micro-batch", type=int, default=262144, help="samples per forward / backward piece of a minibatch")
     args = ap.parse_args()
-    print(json.dumps(run(args.envs, args.steps, args.policy, args.dtype, not args.no_update, args.update_epochs, args.num_minibatches)))
+    print(json.dumps(run(args.envs, args.steps, args.policy, args.dtype, not args.no_update, args.update_epochs, args.num_minibatches, micro_batch=args.micro_batch)))
 
 
 if __name__ == "__main__":

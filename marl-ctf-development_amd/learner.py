@@ -65,12 +65,16 @@ class PPOLearner:
         """agent: a module with the reference's ``get_action_and_value`` / ``get_value`` (policy.CtfPolicy,
         policy_native.CtfPolicyNative or the reference's own Agent).  n_channels: C of the observation (to expand codes)."""
         self.agent, self.n_channels = agent, int(n_channels)
+        self.codes_direct = hasattr(agent, "trunk_codes")  # False: always expand (the reference's own Agent, or to compare the two paths)
         self.args = SimpleNamespace(**dict(DEFAULT_ARGS, **args))
         self.optimizer = torch.optim.Adam(agent.parameters(), lr=self.args.learning_rate, eps=1e-5)  # ppo.py:283
 
     def _planes(self, grids):
-        """uint8 codes [B, G, G] -> float32 planes [B, C, G, G]; planes pass through."""
+        """What the network is fed: uint8 codes [B, G, G] as they are when the agent evaluates them directly (policy.CtfPolicy.trunk_codes:
+        the convolutions as GEMMs over 3x3 patches, no one-hot planes), else expanded to float32 planes [B, C, G, G]; planes pass through."""
         if grids.dim() == 3:
+            if self.codes_direct:
+                return grids
             return expand_codes(grids, self.n_channels).to(torch.float32)
         return grids.to(torch.float32)
 
@@ -107,16 +111,16 @@ class PPOLearner:
                     mb_adv_all = (mb_adv_all - mb_adv_all.mean()) / (mb_adv_all.std() + 1e-8)
                 self.optimizer.zero_grad()
                 piece = n_mb if not micro_batch else int(micro_batch)
-                sums = dict(pg=0.0, v=0.0, ent=0.0, kl=0.0, clip=0.0)
+                sums = torch.zeros(5, dtype=torch.float64, device=b_logprobs.device)  # pg, v, entropy, kl, clip: summed on the device
                 for lo in range(0, n_mb, piece):
                     mb, mb_advantages = mb_all[lo:lo + piece], mb_adv_all[lo:lo + piece]
                     _, newlogprob, entropy, newvalue = agent.get_action_and_value(self._planes(b_grids[mb]), b_metadata_states[mb].to(torch.float32),
-                                                                                  b_use_action_mask[mb], b_actions.long()[mb])
+                                                                                  b_use_action_mask[mb], b_actions[mb].long())
                     logratio = newlogprob - b_logprobs[mb]
                     ratio = logratio.exp()
                     with torch.no_grad():
-                        sums["kl"] += float(((ratio - 1) - logratio).sum())
-                        sums["clip"] += float(((ratio - 1.0).abs() > a.clip_coef).float().sum())
+                        kl_sum = ((ratio - 1) - logratio).sum()
+                        clip_sum = ((ratio - 1.0).abs() > a.clip_coef).float().sum()
                     pg_loss1 = -mb_advantages * ratio
                     pg_loss2 = -mb_advantages * torch.clamp(ratio, 1 - a.clip_coef, 1 + a.clip_coef)
                     pg_sum = torch.max(pg_loss1, pg_loss2).sum()
@@ -131,11 +135,9 @@ class PPOLearner:
                     ent_sum = entropy.sum()
                     # loss = pg_loss - ent_coef * entropy_loss + v_loss * vf_coef with every term a mean over the minibatch
                     ((pg_sum - a.ent_coef * ent_sum + v_sum * a.vf_coef) / n_mb).backward()
-                    sums["pg"] += float(pg_sum)
-                    sums["v"] += float(v_sum)
-                    sums["ent"] += float(ent_sum)
-                pg_loss, v_loss, entropy_loss, approx_kl = sums["pg"] / n_mb, sums["v"] / n_mb, sums["ent"] / n_mb, sums["kl"] / n_mb
-                clipfracs += [sums["clip"] / n_mb]
+                    sums += torch.stack([pg_sum.detach(), v_sum.detach(), ent_sum.detach(), kl_sum, clip_sum]).double()
+                pg_loss, v_loss, entropy_loss, approx_kl, clipfrac = (sums / n_mb).tolist()  # the minibatch's one host round trip
+                clipfracs += [clipfrac]
                 nn.utils.clip_grad_norm_(agent.parameters(), a.max_grad_norm)
                 self.optimizer.step()
                 if progress is not None:

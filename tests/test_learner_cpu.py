@@ -32,8 +32,10 @@ def encode(planes):
     return ((planes[..., 1:, :, :] * k).sum(axis=-3) | (planes[..., 0, :, :] << 7)).astype(np.uint8)
 
 
-@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("compact", [False, "expanded", "direct"])
 def test_gae_and_ppo_update_reproduce_the_reference_learner(compact):
+    """planes as the reference stores them / compact codes expanded to planes per piece / compact codes evaluated directly
+    (policy.CtfPolicy.trunk_codes: table lookup, channels-last convolutions, permuted fc1 columns)"""
     ref = np.load(os.path.join(GOLDEN, "learner_ref.npz"))
     S, E = int(ref["S"]), int(ref["E"])
     planes, metas, masks = _inputs()
@@ -47,6 +49,7 @@ def test_gae_and_ppo_update_reproduce_the_reference_learner(compact):
                    next_metadata_state=t(metas[S * E:S * E + E]), next_done=t(ref["next_done"]))
     rollout.update(dict(grid_codes=grids, next_grid_codes=nxt) if compact else dict(grid_states=grids, next_grid_state=nxt))
     lrn = learner.PPOLearner(net, c, **ARGS)
+    lrn.codes_direct = compact == "direct"
     adv, ret = lrn.advantages(rollout)
     assert np.allclose(adv.numpy(), ref["advantages"], rtol=0, atol=2e-6) and np.allclose(ret.numpy(), ref["returns"], rtol=0, atol=2e-6)
     np.random.seed(7)  # the minibatch order is np.random.shuffle's, as in the reference
