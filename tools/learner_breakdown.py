@@ -37,8 +37,10 @@ def main():
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--pieces", default="16384,65536,262144")
     ap.add_argument("--variants", default="codes,planes")
+    ap.add_argument("--benchmark", action="store_true", help="torch.backends.cudnn.benchmark: MIOpen searches its solvers per shape instead of its heuristic pick")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    torch.backends.cudnn.benchmark = bool(a.benchmark)
     b = batch(a.samples, dev)
     out = {}
     for variant in a.variants.split(","):
