@@ -148,12 +148,13 @@ class ChunkedRolloutGather:
 
 class RolloutHandoff:
     """All-gather of the COMPACT rollout a centralised PPO learner consumes (what ppo.py:46-55,74-84,105-109
-    stores per slot): reward f32, log-prob f32, value f32, action u8, use_action_mask u8 — and, optionally, the observation
+    stores per slot): reward f32, log-prob f32, value f32, action i32, use_action_mask i32 (any integer a caller's policy uses as an
+    action or as a masking decision survives the trip: -1 stays -1) — and, optionally, the observation
     the policy saw in compact form (grid codes u8 [G][G], metadata f16 [M]) — for the trained team's slots of every shard.
 
     The collector hands over one CHUNK of slots at a time (``launch``), as soon as the chunk's last reward is stored; the
     collectives (two per chunk: one float32 pack, one uint8 pack; two more with observations) run asynchronously beside the
-    following env steps.  ``result`` waits and returns tensors in GLOBAL env order: [S, world * E, ...] — rank-major, which
+    following env steps (the "u8" pack of round 2 is an int32 pack now: gloo and RCCL both carry it).  ``result`` waits and returns tensors in GLOBAL env order: [S, world * E, ...] — rank-major, which
     is the global env index because rank r owns envs [r * E, (r + 1) * E).  One rank (and no ``force_collective``): the
     local tensors are returned as they are, nothing is copied."""
 
@@ -178,7 +179,7 @@ class RolloutHandoff:
 
         packs = {
             "f32": torch.stack([local[k][lo:hi].to(torch.float32) for k in self.F32], dim=1).contiguous(),     # [K, 3, E]
-            "u8": torch.stack([local[k][lo:hi].to(torch.uint8) for k in self.U8], dim=1).contiguous(),         # [K, 2, E]
+            "i32": torch.stack([local[k][lo:hi].to(torch.int32) for k in self.U8], dim=1).contiguous(),        # [K, 2, E]
         }
         if self.with_observations:
             packs["codes"] = local["grid_codes"][lo:hi].contiguous()                                            # [K, E, G, G] u8
@@ -204,6 +205,10 @@ class RolloutHandoff:
                 w.wait()
                 chunks.setdefault(name, []).append(out)
         self.pending = []
+        if not chunks:  # collectives on, nothing launched: empty tensors of the right trailing shape, not a KeyError
+            keys = self.F32 + self.U8 + (("grid_codes", "metadata_states") if self.with_observations else ())
+            loc = self.local or {}
+            return {k: loc[k].new_zeros((0, self.world * loc[k].shape[1]) + tuple(loc[k].shape[2:])) for k in keys if k in loc}
 
         def glob(parts, env_dim):
             # parts: [world, K, ..., E, ...] per chunk -> [sum K, ..., world * E, ...] with the rank axis merged into the env axis
@@ -214,9 +219,9 @@ class RolloutHandoff:
             return t.reshape(shape)
 
         f32 = glob(chunks["f32"], 2)  # [S, 3, world * E]
-        u8 = glob(chunks["u8"], 2)
+        i32 = glob(chunks["i32"], 2)
         out = {k: f32[:, i] for i, k in enumerate(self.F32)}
-        out.update({k: u8[:, i].to(torch.float32) for i, k in enumerate(self.U8)})  # the reference stores actions / masks as float32
+        out.update({k: i32[:, i].to(torch.float32) for i, k in enumerate(self.U8)})  # the reference stores actions / masks as float32
         if self.with_observations:
             out["grid_codes"] = glob(chunks["codes"], 1)
             out["metadata_states"] = glob(chunks["meta"], 1).to(torch.float32)

@@ -103,6 +103,16 @@ def _worker(rank, world, port, q):
                 assert "grid_codes" not in got
             nd = ho.gather_once((env_ids % 2).clone())
             assert torch.equal(nd, all_ids % 2)
+        # a sentinel decision / action outside 0..255 survives the trip (the pack is int32), and a hand-off that launched nothing
+        # returns empty tensors of the right trailing shape instead of raising
+        ho = sh.RolloutHandoff(world)
+        ho.launch(0, 4, dict(local, use_action_mask=local["use_action_mask"] - 1.0, actions=local["actions"] + 300.0))
+        got = ho.result()
+        assert torch.equal(got["use_action_mask"], (full % 2)[:4] - 1.0) and torch.equal(got["actions"], (full % 9)[:4] + 300.0)
+        empty = sh.RolloutHandoff(world)
+        empty.launch(0, 0, local)
+        got = empty.result()
+        assert got["rewards"].shape == (0, world * E) and got["actions"].shape == (0, world * E)
         slow = sh.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
         assert slow == float(world)
         # bench.py's self-check of a multi-GPU line: every rank of the job reported one positive time
