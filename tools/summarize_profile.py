@@ -59,6 +59,20 @@ def main():
         body.sort(key=lambda r: (not is_ours(r[0]),))  # stable: ours first, rocprofv3's order (by total time) inside
         with open(os.path.join(root, tag + "_kernel_stats.csv"), "w", newline="") as f:
             csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows([head] + body)
+    # provenance: the bench line the kernel-trace pass printed (its own HIP-event timings, to hold against the trace's averages) and
+    # the exact commands — every file of a tag comes from ONE invocation of the profiling script
+    tlog = os.path.join(src, "trace.log")
+    if os.path.exists(tlog):
+        lines = [l for l in open(tlog, errors="replace") if l.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(root, tag + "_bench_under_rocprof.json"), "w").write(lines[-1])
+    script = "tools/profile_policy.sh" if "policy" in tag else "tools/profile.sh"
+    with open(os.path.join(root, tag + "_PROVENANCE.txt"), "w") as f:
+        f.write(f"{tag}_kernel_stats.csv, {tag}_pmc_summary.json, {tag}_bench_under_rocprof.json: one invocation of `bash {script} {tag}` on one MI355X box "
+                f"(BENCH_ARGS={os.environ.get('PROFILE_BENCH_ARGS', 'see the script')}); passes found: "
+                + ", ".join(p for p in ("trace", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3") if os.path.isdir(os.path.join(src, p)))
+                + ".  kernel_stats averages run over ALL launches of the process (stagger phase, warm-up and secondaries included); the bench line's "
+                  "kernels_ms are HIP events around a sample of the timed region's launches.\n")
     out = {}
     for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
         path = one(os.path.join(src, p, "**", "*_counter_collection.csv"))
