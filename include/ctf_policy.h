@@ -53,6 +53,20 @@ int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* meta_dev, int3
                         const float* conv2_bias_dev, uint16_t* act_dev, const uint16_t* shared_view_selfcell_dev,
                         int32_t device_id, void* stream);
 
+/* The same front as the FORWARD of a training step (the learner's re-evaluation of a minibatch, ppo.py:199-203 -> agent_network.py:30-36):
+ * one sample per row of codes_dev, the activation row as above (bit-identical to ctf_policy_features on the same codes), plus what a
+ * backward pass needs and would otherwise have to recompute, both channels-last so that a library's weight- / data-gradient kernels take
+ * them as they are:
+ *   codes_dev   uint8 [n_samples][G][G]           meta_dev   binary16 bits [n_samples][meta_len]
+ *   act_dev     bf16 [n_samples][ctf_policy_act_stride()]
+ *   h0_dev      bf16 [n_samples][G*G][16]         the one-hot input image (planes C..15 zero)
+ *   h1_dev      bf16 [n_samples][(G-2)^2][16]     tanh(conv1)
+ * all 16-byte aligned; grid_size 11 or 15. */
+int ctf_policy_features_train(const uint8_t* codes_dev, const uint16_t* meta_dev, int64_t n_samples, int32_t grid_size,
+                              int32_t meta_len, const void* conv1_frag_dev, const float* conv1_bias_dev,
+                              const void* conv2_frag_dev, const float* conv2_bias_dev, uint16_t* act_dev, uint16_t* h0_dev,
+                              uint16_t* h1_dev, int32_t device_id, void* stream);
+
 /* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
  *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)
  *   logits += (mask - 1) * 1e9 with mask = [1]*5 + [0]*(A-5) where the decision is 1, all ones otherwise

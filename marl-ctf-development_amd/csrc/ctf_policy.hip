@@ -53,6 +53,9 @@ struct PolicyArgs {
     int32_t n_envs, N, G, M, Kp, n_sel;
     uint64_t sel_pack;        // nibble k = agent index of selection slot k
     uint32_t inv_g1, inv_g2;  // ceil(65536 / G1), ceil(65536 / G2): exact for the position ranges used (checked on the host)
+    // TRAIN instantiation only (ctf_policy_features_train): what a backward pass needs beside the activation row, channels-last
+    uint16_t* h0_out;         // bf16 [S][G*G][16]: the one-hot input image (planes C..15 are zero)
+    uint16_t* h1_out;         // bf16 [S][(G-2)^2][16]: tanh(conv1)
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -135,7 +138,18 @@ __device__ __forceinline__ void pol_wait_codes(PolCodes<NP>& c) {
 // the same wait for further registers (an s_waitcnt that follows one with the same count costs nothing)
 #define POL_WAIT_VM1(N, r0) asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(r0) : "n"(N) : "memory")
 
-template <int TG>
+// One LDS image of this wave ([2 channel halves][rows][8 channels] bf16) -> global memory channels-last ([rows][16 channels]): 16-byte
+// pieces, consecutive lanes write consecutive pieces.
+__device__ __forceinline__ void pol_store_image(const uint8_t* img, int half_bytes, int rows, uint16_t* out, int lane) {
+    // piece idx = lane + 64 k: half idx & 1 = lane & 1, row idx >> 1 = (lane >> 1) + 32 k.  Rolled: unrolled, the fourteen address
+    // pairs spill, and a scratch reload is a vmcnt(0) — every store of the sample drained before the next one may issue.
+    const uint8_t* src = img + (lane & 1) * half_bytes + (lane >> 1) * 16;
+    uint8_t* dst = (uint8_t*)out + lane * 16;
+#pragma unroll 1
+    for (int idx = lane; idx < 2 * rows; idx += WAVE, src += 32 * 16, dst += WAVE * 16) *(u32x4_t*)dst = *(const u32x4_t*)src;
+}
+
+template <int TG, bool TRAIN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_policy_features(PolicyArgs a) {
     extern __shared__ uint32_t lds[];
     const int G = TG ? TG : a.G;
@@ -260,6 +274,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        if (TRAIN) pol_store_image(h0, H0A, GG, a.h0_out + (size_t)s * GG * 16, lane);
 
         // ---- conv1 + tanh -> h1.  (Positions >= P1 of the last tile read past h0 into h1 — inside this wave's LDS — and
         // land in h1 rows >= P1, which nothing reads.)
@@ -308,6 +323,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        if (TRAIN) pol_store_image(h1, H1A, P1, a.h1_out + (size_t)s * P1 * 16, lane);
 
         // ---- conv2 + tanh -> activation row
         const int T2 = (P2 + 31) >> 5;
@@ -355,6 +371,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             // The next sample's inputs, issued at the top of this sample, are older than its 1 + 4 T2 stores: a counted wait
             // leaves those stores in flight.  The wait sits HERE, in the iteration that issued the loads — the compiler knows
             // nothing about their latency and is free to copy the destination registers at the loop's back edge.
+            // (TRAIN issues 14 more stores — the two images — between the loads and the last of these; waiting with the same count
+            // is the conservative side: at most the youngest 1 + 4 T2 operations stay in flight, all of them stores.)
             constexpr int STORES = 1 + 4 * ((((TG - 4) * (TG - 4)) + 31) >> 5);
             pol_wait_codes<STORES, NP>(nextc);
             POL_WAIT_VM1(STORES, nextm);
@@ -892,6 +910,7 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
     a.n_envs = n_envs; a.N = n_agents; a.G = grid_size; a.M = meta_len; a.n_sel = n_sel;
     a.Kp = ctf_policy_act_stride(grid_size, meta_len);
     a.sel_pack = 0;
+    a.h0_out = nullptr; a.h1_out = nullptr;
     for (int k = 0; k < n_sel; k++) {
         if (agent_sel[k] < 0 || agent_sel[k] >= n_agents) return pfail("agent_sel entry out of range");
         a.sel_pack |= (uint64_t)agent_sel[k] << (4 * k);
@@ -959,6 +978,59 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
     } else {
         if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_features<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (err == hipSuccess) hipLaunchKernelGGL(k_policy_features<0>, dim3(blocks), dim3(wpb * WAVE), sh, st, a);
+    }
+    if (err == hipSuccess) err = hipGetLastError();
+    if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err != hipSuccess) return pfail(hipGetErrorString(err));
+    return 0;
+}
+
+extern "C" int ctf_policy_features_train(const uint8_t* codes_dev, const uint16_t* meta_dev, int64_t n_samples, int32_t grid_size,
+                                         int32_t meta_len, const void* conv1_frag_dev, const float* conv1_bias_dev,
+                                         const void* conv2_frag_dev, const float* conv2_bias_dev, uint16_t* act_dev, uint16_t* h0_dev,
+                                         uint16_t* h1_dev, int32_t device_id, void* stream) {
+    if (!codes_dev || !meta_dev || !conv1_frag_dev || !conv1_bias_dev || !conv2_frag_dev || !conv2_bias_dev || !act_dev || !h0_dev || !h1_dev)
+        return pfail("null argument");
+    if (grid_size != 15 && grid_size != 11) return pfail("the training front is built for grid_size 11 and 15 (the reference's maps)");
+    if (n_samples < 1 || n_samples > 0x7FFFFFFF) return pfail("n_samples out of range");
+    if (meta_len < 2 || (meta_len & 1)) return pfail("meta_len must be even (2N + 6)");
+    if (((uintptr_t)act_dev & 15) || ((uintptr_t)h0_dev & 15) || ((uintptr_t)h1_dev & 15) || ((uintptr_t)meta_dev & 3))
+        return pfail("act_dev / h0_dev / h1_dev must be 16-byte, meta_dev 4-byte aligned");
+    PolicyArgs a;
+    a.codes = codes_dev; a.meta = meta_dev; a.act = act_dev;
+    a.w1frag = (const u32x4_t*)conv1_frag_dev; a.b1 = conv1_bias_dev;
+    a.w2frag = (const u32x4_t*)conv2_frag_dev; a.b2 = conv2_bias_dev;
+    a.n_envs = (int32_t)n_samples; a.N = 1; a.G = grid_size; a.M = meta_len; a.n_sel = 1;  // every row of codes_dev is one sample
+    a.Kp = ctf_policy_act_stride(grid_size, meta_len);
+    a.sel_pack = 0;
+    a.h0_out = h0_dev; a.h1_out = h1_dev;
+    const int G1 = grid_size - 2, G2 = grid_size - 4;
+    a.inv_g1 = (65536 + G1 - 1) / G1;
+    a.inv_g2 = (65536 + G2 - 1) / G2;
+    for (int p = 0; p < G1 * G1; p++)
+        if ((int)(((uint32_t)p * a.inv_g1) >> 16) != p / G1) return pfail("internal: reciprocal of G-2 not exact");
+    for (int p = 0; p < G2 * G2; p++)
+        if ((int)(((uint32_t)p * a.inv_g2) >> 16) != p / G2) return pfail("internal: reciprocal of G-4 not exact");
+    const int n_cus = policy_n_cus(device_id);
+    if (!n_cus) return pfail("hipGetDeviceProperties failed");
+    int dev_prev = 0;
+    if (hipGetDevice(&dev_prev) != hipSuccess) return pfail("hipGetDevice failed");
+    if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
+    const int per_wave = pol_h0_bytes(grid_size) + pol_h1_bytes(grid_size);
+    const int wpb = 4;
+    const size_t sh = (size_t)wpb * per_wave;
+    int per_cu = (int)((160 * 1024) / sh);
+    if (per_cu * wpb > 12) per_cu = 12 / wpb;  // 3 waves per SIMD, as in ctf_policy_features
+    int64_t blocks = (n_samples + wpb - 1) / wpb;
+    if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipSuccess;
+    if (grid_size == 15) {
+        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_features<15, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) hipLaunchKernelGGL((k_policy_features<15, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+    } else {
+        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_features<11, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) hipLaunchKernelGGL((k_policy_features<11, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
     }
     if (err == hipSuccess) err = hipGetLastError();
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);

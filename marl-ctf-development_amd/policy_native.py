@@ -96,7 +96,44 @@ def tail_fragments(fc2_w, fc2_b, action_w, action_b, value_w, value_b):
     return f2, (np.asarray(fc2_b, np.float64) * _TWO_LOG2E).astype(np.float32), fh, bh
 
 
+class _NativeFront(torch.autograd.Function):
+    """conv1 -> tanh -> conv2 -> tanh -> flatten ++ metadata of a training step with the native kernel as the FORWARD
+    (ctf_policy_features_train: the activation row fc1 consumes, plus the one-hot image and tanh(conv1) channels-last) and the
+    library's convolution gradients on exactly those tensors as the backward.  MIOpen's forward convolutions, the table lookup of
+    the planes, two tanh kernels and the bias adds leave the learner's pass; its weight- and data-gradient kernels stay."""
+
+    @staticmethod
+    def forward(ctx, net, codes, meta, w1, b1, w2, b2):
+        act, h0, h1 = net.features_train(codes, meta)
+        ctx.save_for_backward(act, h0, h1, w2)
+        ctx.geom = (net.grid_size, int(w1.shape[1]))
+        return act
+
+    @staticmethod
+    def backward(ctx, d_act):
+        act, h0, h1, w2 = ctx.saved_tensors
+        g, c_in = ctx.geom
+        g1, g2 = g - 2, g - 4
+        p2 = g2 * g2
+        pp = (p2 + 31) // 32 * 32
+        b = act.shape[0]
+        bf, cl = torch.bfloat16, torch.channels_last
+        conv_bwd = torch.ops.aten.convolution_backward
+        h2, d2 = act[:, :32 * pp], d_act[:, :32 * pp].to(bf)
+        dz2 = d2 * (1 - h2 * h2)  # tanh'; columns ((c / 4) * PP + p) * 4 + c % 4 -> [B, G2, G2, 32] = channels-last memory of [B, 32, G2, G2]
+        dz2 = dz2.view(b, 8, pp, 4)[:, :, :p2].permute(0, 2, 1, 3).reshape(b, g2, g2, 32).permute(0, 3, 1, 2)
+        h1i = h1.view(b, g1, g1, 16).permute(0, 3, 1, 2)
+        dh1, dw2, db2 = conv_bwd(dz2, h1i, w2.to(bf).contiguous(memory_format=cl), [32], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, True, True])
+        dz1 = dh1 * (1 - h1i * h1i)
+        h0i = h0.view(b, g, g, 16).permute(0, 3, 1, 2)
+        w1_shape = torch.empty((16, 16, 3, 3), dtype=bf, device=act.device).contiguous(memory_format=cl)  # only its shape is used
+        _, dw1, db1 = conv_bwd(dz1, h0i, w1_shape, [16], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
+        return None, None, None, dw1[:, :c_in].float(), db1.float(), dw2.float(), db2.float()
+
+
 class CtfPolicyNative(CtfPolicy):
+    native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
+
     def __init__(self, n_actions, n_channels, grid_size, metadata_size, seed=None):
         super().__init__(n_actions, n_channels, grid_size, metadata_size, compute_dtype=torch.bfloat16)
         self.grid_size, self.metadata_size, self.n_channels = grid_size, metadata_size, n_channels
@@ -177,6 +214,7 @@ class CtfPolicyNative(CtfPolicy):
                 f1=up(f1, bf), b1=up(b1), f2=up(f2, bf), b2=up(b2),
                 fc1_w=fc1.to(bf).contiguous(), fc1_b=(self.fc1.bias.float() * _TWO_LOG2E).to(bf),
                 t2=up(t2, bf), tb2=up(tb2), th=up(th, bf), tbh=up(tbh),
+                col_src=torch.from_numpy(np.maximum(order, 0)).to(dev), col_keep=keep.to(torch.float32),
             )
             assert lib.ctf_policy_act_stride(self.grid_size, self.metadata_size) == len(order)
         return self
@@ -224,6 +262,41 @@ class CtfPolicyNative(CtfPolicy):
         if rc != 0:
             raise _abi.CtfLibraryError("ctf_policy_features: " + (p["lib"].ctf_policy_last_error() or b"").decode())
         return out
+
+    # -- the forward of a training step ----------------------------------------------------------------
+    def features_train(self, codes, meta):
+        """codes uint8 [B, G, G], meta float16 [B, M] -> (activation rows bf16 [B, Kp] as features_from_codes writes them, the one-hot
+        input image bf16 [B, G*G, 16], tanh(conv1) bf16 [B, (G-2)^2, 16]) — ctf_policy_features_train."""
+        p = self._ready()
+        b, g = int(codes.shape[0]), self.grid_size
+        if not (codes.is_cuda and codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape[1:]) == (g, g)):
+            raise ValueError("codes must be a contiguous uint8 CUDA tensor [B, G, G]")
+        if not (meta.is_cuda and meta.dtype == torch.float16 and meta.is_contiguous() and tuple(meta.shape) == (b, self.metadata_size)):
+            raise ValueError("meta must be a contiguous float16 CUDA tensor [B, M]")
+        new = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=codes.device)
+        act, h0, h1 = new(b, p["kp"]), new(b, g * g, 16), new(b, (g - 2) ** 2, 16)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        rc = p["lib"].ctf_policy_features_train(ptr(codes), ptr(meta), b, g, self.metadata_size, ptr(p["f1"]), ptr(p["b1"]), ptr(p["f2"]),
+                                                ptr(p["b2"]), ptr(act), ptr(h0), ptr(h1), codes.device.index,
+                                                C.c_void_p(torch.cuda.current_stream(codes.device).cuda_stream))
+        if rc != 0:
+            raise _abi.CtfLibraryError("ctf_policy_features_train: " + (p["lib"].ctf_policy_last_error() or b"").decode())
+        return act, h0, h1
+
+    def trunk_codes(self, codes, metadata):
+        """CtfPolicy.trunk_codes; on a HIP device with gradients enabled the two convolutions' forward is the native front
+        (_NativeFront) and fc1 runs on its activation rows with the weight columns gathered into the kernel's order."""
+        if not (self.native_training and codes.is_cuda and torch.is_grad_enabled() and self.grid_size in (11, 15)):
+            return super().trunk_codes(codes, metadata)
+        p = self._ready()
+        act = _NativeFront.apply(self, codes.contiguous(), metadata.to(torch.float16).contiguous(), self.conv1.weight, self.conv1.bias,
+                                 self.conv2.weight, self.conv2.bias)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            w = self.fc1.weight.index_select(1, p["col_src"]) * p["col_keep"]  # [256, Kp]: zero weight on the row's padding
+            x = torch.tanh(torch.nn.functional.linear(act, w, self.fc1.bias))
+            x = torch.tanh(self.fc2(x))
+            value, logits = self.value_head(x), self.action_head(x)
+        return value.float(), logits.float()
 
     def _features_tuned(self, codes, meta, agent_idx, shared_view, self_cells, tries=6, good_enough=0.9):
         """features_from_codes into a persistent activation buffer.  About half of all >1 GiB allocations on this pool stream

@@ -362,6 +362,49 @@ def test_kernel_side_weights_follow_parameter_updates():
     assert float((l1 - l2).abs().max()) < 0.15
 
 
+@pytest.mark.parametrize("g,c,n", [(15, 14, 8), (11, 8, 4)])
+def test_training_forward_through_the_native_front_gives_the_stock_paths_outputs_and_gradients(g, c, n):
+    """CtfPolicyNative.trunk_codes with gradients = the native front as the forward (ctf_policy_features_train: activation rows
+    bit-identical to the inference kernel's, plus the one-hot image and tanh(conv1) channels-last) and the library's convolution
+    gradients as the backward, against the same module through the stock channels-last path (native_training = False)."""
+    rng = np.random.default_rng(g)
+    m, b = 2 * n + 6, 777  # a partial wave and a partial block at the end
+    low = rng.integers(0, c, (b, g, g)).astype(np.uint8) * (rng.random((b, g, g)) < 0.3)
+    codes = low.copy()
+    cell = rng.integers(0, g * g, b)
+    codes.reshape(b, -1)[np.arange(b), cell] |= 128
+    codes_t = torch.tensor(codes, device="cuda")
+    meta_t = torch.tensor(rng.random((b, m)).astype(np.float16), device="cuda")
+    net = fill_(native.CtfPolicyNative(9, c, g, m)).cuda()
+    # the forward's three outputs
+    act, h0, h1 = net.features_train(codes_t, meta_t)
+    ref = net.features_from_codes(codes_t.reshape(b, 1, g, g), meta_t.reshape(b, 1, m), [0])
+    assert torch.equal(act, ref)
+    planes = torch.tensor(pkg.expand_codes(codes, c)).cuda()
+    assert torch.equal(h0.reshape(b, g, g, 16)[..., :c].permute(0, 3, 1, 2).float(), planes.float()) and float(h0[..., c:].abs().max()) == 0.0
+    w1, b1 = (net.conv1.weight.detach().double() * S).to(torch.bfloat16).double(), (net.conv1.bias.detach().double() * S).float().double()
+    h1_want = (1.0 - 2.0 / (torch.exp2(torch.nn.functional.conv2d(planes.double(), w1, b1)) + 1.0)).permute(0, 2, 3, 1).reshape(b, (g - 2) ** 2, 16)
+    assert float((h1.double() - h1_want).abs().max()) <= 2.0 ** -7
+    # outputs and gradients of a training step, both ways
+    weight = torch.tensor(rng.standard_normal((b, 10)), device="cuda", dtype=torch.float32)
+
+    def grads(native_training):
+        net.native_training = native_training
+        net.zero_grad()
+        value, logits = net(codes_t, meta_t.float())
+        loss = (torch.cat((logits, value), dim=1) * weight).sum() / b
+        loss.backward()
+        return loss.item(), logits.detach().clone(), {k: q.grad.detach().clone() for k, q in net.named_parameters()}
+
+    l0, lg0, g0 = grads(False)
+    l1, lg1, g1 = grads(True)
+    assert float((lg0 - lg1).abs().max()) <= 6e-2 and abs(l0 - l1) <= 2e-2 * max(1.0, abs(l0))
+    for k in g0:
+        den = float(g0[k].norm())
+        rel = float((g0[k] - g1[k]).norm()) / max(den, 1e-12)
+        assert rel <= 3e-2, (k, rel, den)  # bf16 operands on both sides; the two paths round at different places
+
+
 def test_native_path_fails_loudly_off_gpu():
     net = native.CtfPolicyNative(9, 14, 15, 22)
     with pytest.raises(pkg._abi.CtfLibraryError):

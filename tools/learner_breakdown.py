@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where the learner's time goes (configs[4]'s update, learner.PPOLearner.optimise on the 8_arena shapes): sample-passes per
 second of one epoch over a synthetic batch, for the two ways of feeding the network (one-hot planes through the stock
-convolutions / compact codes through the patch GEMMs of policy.CtfPolicy.trunk_codes) and several piece sizes, plus a
+convolutions / compact codes: native front as the forward + MIOpen gradients ("codes"), stock channels-last modules
+("codes_stock")) and several piece sizes, plus a
 forward / backward split of one piece by torch.cuda events.
 
     python tools/learner_breakdown.py [--samples 1048576]        (GPU box)
@@ -50,7 +51,8 @@ def main():
             torch.manual_seed(0)
             net = pkg.policy_native.CtfPolicyNative(9, C, G, M).to(dev)
             lrn = learner.PPOLearner(net, C, update_epochs=1, num_minibatches=4)
-            lrn.codes_direct = variant == "codes"
+            lrn.codes_direct = variant.startswith("codes")
+            net.native_training = variant == "codes"  # codes_stock: the stock channels-last modules also for the forward
             n_warm = min(a.samples, 4 * piece)
             run = lambda n: lrn.optimise(b["grids"][:n], b["meta"][:n], b["logp"][:n], b["act"][:n], b["mask"][:n], b["adv"][:n], b["ret"][:n], b["val"][:n],
                                          micro_batch=piece)

@@ -19,7 +19,8 @@ for variant in variants:
     if variant == "planes_cl":
         net = net.to(memory_format=torch.channels_last)
     lrn = lb.learner.PPOLearner(net, lb.C)
-    lrn.codes_direct = variant == "codes"
+    lrn.codes_direct = variant.startswith("codes")
+    net.native_training = variant == "codes"
 
     def step():
         x = lrn._planes(b["grids"])
