@@ -65,8 +65,8 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         micro = min(micro_batch, samples // num_minibatches)
         # A minibatch is evaluated in pieces (learner.optimise(micro_batch=): the same update, gradients accumulated).  MIOpen
         # compiles its convolution kernels on first use of every (batch, C, H, W) shape (up to a minute on a fresh box), so the
-        # warm-up runs one such piece untimed.  Pieces of 262 144 samples: 8.0 M sample-passes/s against 4.5 / 6.9 M at 16 384 /
-        # 65 536 through the channels-last path of policy.CtfPolicy.trunk_codes (tools/learner_breakdown.py; 9 GB of activations)
+        # warm-up runs one such piece untimed.  Pieces of 262 144 samples: 11.4 M sample-passes/s against 9.5 M at 65 536
+        # (tools/learner_breakdown.py; 13 GB of activations)
         log(f"rollout {rollout_s:.3f} s; warm-up piece of {micro} samples (MIOpen compiles its kernels) ...")
         throwaway = learner.PPOLearner(copy.deepcopy(nets[0]), vec.N_CHANNELS, update_epochs=1, num_minibatches=1)
         adv, ret = throwaway.advantages(out)
@@ -87,8 +87,9 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
             "update_sample_passes_per_s": samples * update_epochs / update_s,
             "value": envs * steps / (rollout_s + update_s), "learner_share_of_time": update_s / (rollout_s + update_s),
             "losses_v_pg_entropy": [float(x) for x in losses],
-            "note": "the learner is the reference's PPO update (ppo.py:174-242) in PyTorch on the compact rollout: one-hot planes by table "
-                    "lookup, channels-last bf16 convolutions (MIOpen), hipBLASLt GEMMs; it still dominates the iteration",
+            "note": "the learner is the reference's PPO update (ppo.py:174-242) on the compact rollout: the native conv front as the forward "
+                    "(ctf_policy_features_train), fused tanh' + bias-gradient kernels, MIOpen's channels-last weight / data gradients, "
+                    "hipBLASLt GEMMs (policy_native._NativeFront); it still dominates the iteration",
         })
     else:
         res["value"] = res["rollout_env_steps_per_s"]

@@ -67,6 +67,18 @@ int ctf_policy_features_train(const uint8_t* codes_dev, const uint16_t* meta_dev
                               const void* conv2_frag_dev, const float* conv2_bias_dev, uint16_t* act_dev, uint16_t* h0_dev,
                               uint16_t* h1_dev, int32_t device_id, void* stream);
 
+/* The element-wise steps of that front's backward pass, tanh'(x) * incoming gradient = g * (1 - h^2), one pass over memory each:
+ *   ctf_policy_tanh_grad       grad, act, out: bf16 arrays of n_elems (whole 16-channel positions) in the same layout — tanh(conv1),
+ *                              channels-last
+ *   ctf_policy_act_grad_rows   d_act, act: bf16 [n_samples][ctf_policy_act_stride()] (the activation matrix and the gradient fc1 hands
+ *                              back); out: bf16 [n_samples][(G-4)^2][32], channels-last — what a library's convolution gradients take
+ *   bias_grad_dev              NULL, or float [16] / [32]: += the per-channel sums of `out` in float32 (the convolution's bias gradient;
+ *                              the caller zeroes it) */
+int ctf_policy_tanh_grad(const uint16_t* grad_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_elems, float* bias_grad_dev,
+                         void* stream);
+int ctf_policy_act_grad_rows(const uint16_t* d_act_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_samples,
+                             int32_t grid_size, int32_t meta_len, float* bias_grad_dev, void* stream);
+
 /* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
  *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)
  *   logits += (mask - 1) * 1e9 with mask = [1]*5 + [0]*(A-5) where the decision is 1, all ones otherwise

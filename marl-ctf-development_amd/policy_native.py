@@ -106,29 +106,38 @@ class _NativeFront(torch.autograd.Function):
     def forward(ctx, net, codes, meta, w1, b1, w2, b2):
         act, h0, h1 = net.features_train(codes, meta)
         ctx.save_for_backward(act, h0, h1, w2)
-        ctx.geom = (net.grid_size, int(w1.shape[1]))
+        ctx.geom = (net.grid_size, int(w1.shape[1]), net.metadata_size, net._ready()["lib"])
         return act
 
     @staticmethod
     def backward(ctx, d_act):
         act, h0, h1, w2 = ctx.saved_tensors
-        g, c_in = ctx.geom
+        g, c_in, m, lib = ctx.geom
         g1, g2 = g - 2, g - 4
-        p2 = g2 * g2
-        pp = (p2 + 31) // 32 * 32
-        b = act.shape[0]
+        b, dev = act.shape[0], act.device
         bf, cl = torch.bfloat16, torch.channels_last
         conv_bwd = torch.ops.aten.convolution_backward
-        h2, d2 = act[:, :32 * pp], d_act[:, :32 * pp].to(bf)
-        dz2 = d2 * (1 - h2 * h2)  # tanh'; columns ((c / 4) * PP + p) * 4 + c % 4 -> [B, G2, G2, 32] = channels-last memory of [B, 32, G2, G2]
-        dz2 = dz2.view(b, 8, pp, 4)[:, :, :p2].permute(0, 2, 1, 3).reshape(b, g2, g2, 32).permute(0, 3, 1, 2)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        d_act = d_act.to(bf).contiguous()
+        # tanh' of conv2's output: rows of the activation matrix in, [B, G2, G2, 32] = channels-last memory of [B, 32, G2, G2] out
+        dz2 = torch.empty((b, g2, g2, 32), dtype=bf, device=dev)
+        db = torch.zeros(48, dtype=torch.float32, device=dev)  # both bias gradients: summed by the two kernels, in float32
+        db2, db1 = db[:32], db[32:]
+        if lib.ctf_policy_act_grad_rows(ptr(d_act), ptr(act), ptr(dz2), b, g, m, ptr(db2), stream) != 0:
+            raise _abi.CtfLibraryError("ctf_policy_act_grad_rows: " + (lib.ctf_policy_last_error() or b"").decode())
+        dz2 = dz2.permute(0, 3, 1, 2)
         h1i = h1.view(b, g1, g1, 16).permute(0, 3, 1, 2)
-        dh1, dw2, db2 = conv_bwd(dz2, h1i, w2.to(bf).contiguous(memory_format=cl), [32], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, True, True])
-        dz1 = dh1 * (1 - h1i * h1i)
+        dh1, dw2, _ = conv_bwd(dz2, h1i, w2.to(bf).contiguous(memory_format=cl), [32], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, True, False])
+        dh1 = dh1.contiguous(memory_format=cl)
+        dz1 = torch.empty((b, g1, g1, 16), dtype=bf, device=dev)
+        if lib.ctf_policy_tanh_grad(ptr(dh1), ptr(h1), ptr(dz1), dz1.numel(), ptr(db1), stream) != 0:
+            raise _abi.CtfLibraryError("ctf_policy_tanh_grad: " + (lib.ctf_policy_last_error() or b"").decode())
+        dz1 = dz1.permute(0, 3, 1, 2)
         h0i = h0.view(b, g, g, 16).permute(0, 3, 1, 2)
         w1_shape = torch.empty((16, 16, 3, 3), dtype=bf, device=act.device).contiguous(memory_format=cl)  # only its shape is used
-        _, dw1, db1 = conv_bwd(dz1, h0i, w1_shape, [16], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
-        return None, None, None, dw1[:, :c_in].float(), db1.float(), dw2.float(), db2.float()
+        _, dw1, _ = conv_bwd(dz1, h0i, w1_shape, [16], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
+        return None, None, None, dw1[:, :c_in].float(), db1, dw2.float(), db2
 
 
 class CtfPolicyNative(CtfPolicy):

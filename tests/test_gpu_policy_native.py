@@ -388,21 +388,26 @@ def test_training_forward_through_the_native_front_gives_the_stock_paths_outputs
     # outputs and gradients of a training step, both ways
     weight = torch.tensor(rng.standard_normal((b, 10)), device="cuda", dtype=torch.float32)
 
-    def grads(native_training):
-        net.native_training = native_training
+    def grads(native_training, dtype=torch.bfloat16):
+        net.native_training, net.compute_dtype = native_training, dtype
         net.zero_grad()
         value, logits = net(codes_t, meta_t.float())
         loss = (torch.cat((logits, value), dim=1) * weight).sum() / b
         loss.backward()
         return loss.item(), logits.detach().clone(), {k: q.grad.detach().clone() for k, q in net.named_parameters()}
 
+    _, lgf, gf = grads(False, torch.float32)  # the float32 network: what both bf16 paths approximate
     l0, lg0, g0 = grads(False)
     l1, lg1, g1 = grads(True)
-    assert float((lg0 - lg1).abs().max()) <= 6e-2 and abs(l0 - l1) <= 2e-2 * max(1.0, abs(l0))
-    for k in g0:
-        den = float(g0[k].norm())
-        rel = float((g0[k] - g1[k]).norm()) / max(den, 1e-12)
-        assert rel <= 3e-2, (k, rel, den)  # bf16 operands on both sides; the two paths round at different places
+    assert bool(((lg0 - lg1).abs() <= 4e-2 + 2.0 ** -7 * lg0.abs()).all()) and abs(l0 - l1) <= 2e-2 * max(1.0, abs(l0))  # bf16 outputs
+    report = {}
+    for k in gf:
+        den = max(float(gf[k].norm()), 1e-12)
+        e_stock, e_native = float((g0[k] - gf[k]).norm()) / den, float((g1[k] - gf[k]).norm()) / den
+        report[k] = (round(e_stock, 4), round(e_native, 4))
+        # as close to the float32 gradients as the stock bf16 path is (the two round at different places)
+        assert e_native <= 1.5 * e_stock + 1e-2 and e_native <= 5e-2, (k, e_stock, e_native)
+    print("relative gradient error against float32 (stock bf16 path, native front):", report)
 
 
 def test_native_path_fails_loudly_off_gpu():
