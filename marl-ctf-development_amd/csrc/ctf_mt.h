@@ -17,10 +17,11 @@
 //   end of the block is still one contiguous load.
 //
 // A step loads ~128 digest bytes per env with three load instructions and stores two positions.  When the consumer leaves a
-// ring, a bulk kernel (k_rng_refill, one wave per ring, every few steps) regenerates it from the ring that is current now —
-// whole blocks, fully coalesced, 8 bytes of traffic per word — and writes its digests.  ring_refill below is that
-// regeneration, written once for 64 lanes (the bulk kernel, staging in LDS), for one lane (the step kernel's safety net, should a
-// ring ever be needed before the bulk kernel got to it) and for the host (tests/hostsim).
+// ring it marks it stale (rngready), and one wave of a later launch — a TAIL BLOCK of k_step, or k_rng_refill after seeding /
+// import — regenerates it from the ring that is current now: whole blocks, fully coalesced, 8 bytes of traffic per word, and
+// writes its digests.  ring_next_block / ring_digest / ring_link below are that regeneration, written once for 64 lanes (staging
+// in LDS), for one lane (the step kernel's safety net, should a ring ever be needed before a tail block got to it) and for the
+// host (tests/hostsim).
 //
 // Counter mode (CTF_RNG_COUNTER): the same rings and digests, but block k of a stream is words [624 k, 624 k + 624) of
 // Philox4x32-10(key = the stream's seed, counter = (word / 4, stream, "CTF1")) and the words are used as they are (no tempering).

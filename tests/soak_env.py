@@ -17,9 +17,10 @@ import oracle  # noqa: E402  (test infrastructure: this tool is a checker, not t
 pkg = importlib.import_module("marl-ctf-development_amd")
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+rng_mode = sys.argv[3] if len(sys.argv) > 3 else "mt19937"  # or "counter"
 kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
 seeds = np.arange(E, dtype=np.uint64) + 77
-vec = pkg.VecGridworldCtf(E, device=0, py_seeds=seeds, np_seeds=seeds, **kw)
+vec = pkg.VecGridworldCtf(E, device=0, py_seeds=seeds, np_seeds=seeds, rng_mode=rng_mode, **kw)
 sample = np.linspace(0, E - 1, 32).astype(int)
 refs = {int(e): oracle.OracleEnv(vec.cfg) for e in sample}
 for e, r in refs.items():
@@ -48,5 +49,13 @@ for t in range(steps):
                 bad += 1
     if t % 500 == 0:
         print(f"step {t} status {vec.status()} mismatches {bad} elapsed {time.time() - t0:.1f}s", flush=True)
+# where the generators stand after all those ring switches: the standard-form MT19937 states (or the words consumed of the Philox tapes)
+ctr = vec.get_rng_counters().cpu().numpy() if rng_mode == "counter" else None
+for e in sample:
+    if rng_mode == "counter":
+        bad += tuple(int(x) for x in ctr[int(e)]) != tuple(int(x) for x in refs[int(e)].get_rng_counters())
+    else:
+        (py, npw), (opy, onp) = vec.get_rng_state(int(e)), refs[int(e)].get_rng_state()
+        bad += not (np.array_equal(py, opy) and np.array_equal(npw, onp))
 print("done", steps, "steps; status", vec.status(), "mismatches", bad, flush=True)
 sys.exit(1 if bad or vec.status() else 0)
