@@ -381,9 +381,14 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= n_step_blocks) {
+#ifndef STEP_TAIL_FIRST
+#define STEP_TAIL_FIRST 0  // 1 (measured, not shipped): the ring-regenerating blocks at the HEAD of the grid instead of its tail
+#endif
+    const int n_tail_blocks = (int)gridDim.x - n_step_blocks;
+    const int sb = STEP_TAIL_FIRST ? (int)blockIdx.x - n_tail_blocks : (int)blockIdx.x;  // this step block's index
+    if (STEP_TAIL_FIRST ? sb < 0 : sb >= n_step_blocks) {
         // ---- a TAIL block (see tail_block): these start as step blocks retire — the LDS is full until then
-        tail_block(cfg, p, (int)blockIdx.x - n_step_blocks, phase, lane, lds);
+        tail_block(cfg, p, STEP_TAIL_FIRST ? (int)blockIdx.x : sb - n_step_blocks, phase, lane, lds);
         return;
     }
     STEP_STAMP(0);
@@ -393,7 +398,7 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
                                        ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
 #endif
     const int g = lane / W, j = lane % W;
-    const int env0 = blockIdx.x * EPW;
+    const int env0 = sb * EPW;
     const int nvalid = min(EPW, cfg.n_envs - env0);
     const int SLB = step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     const int SLW = SLB / 4, GW = cfg.GS / 4, RW = cfg.RS / 4;
