@@ -35,6 +35,8 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         nets = [pkg.policy.CtfPolicy(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN, compute_dtype=dt).to(dev) for _ in range(2)]
     log = lambda msg: print(f"[bench_rollout {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
     col = pkg.BatchedRolloutCollector(vec, steps, 0)
+    if os.environ.get("CTF_ROLLOUT_OVERLAP") == "1":  # A/B only: the opponent's conv front on a second stream (measured slower)
+        col.overlap_teams = True
     col.collect(*nets)  # warm-up (MIOpen kernel selection, buffer placement)
     log("warm-up rollout done")
     torch.cuda.synchronize()

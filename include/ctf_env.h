@@ -194,7 +194,16 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  *   reverse_mask bit i = reverse_grid for agent i; CTF_REVERSE_DEFAULT = (team(i) == 1), the value
  *                every caller in the reference passes (ppo.py:69,87; utils.py:535)
  * One launch: k_observe_tiles (one wave per 8 KiB of the flat buffer) when an env's block is a multiple of 16 bytes and at
- * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way. */
+ * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way.
+ *
+ * PLACEMENT of obs_dev (the caller's buffer, so the caller's business): on MI355X roughly one hipMalloc allocation
+ * of > 1 GiB in ten is of a kind this launch streams into at 0.82 of the HBM peak, the others cost it 15-20 % — a property of the
+ * allocation's physical backing, independent from one allocation to the next even after a free.  A caller that cares allocates a
+ * candidate, times ctf_observe into it against a plain fill of the same bytes (the fill does not depend on the kind: render / fill
+ * <= 1.07 is the fast kind), frees it if it is slow and tries again.  The Python facade does exactly that on first use of its
+ * observation buffer: knobs placement_tries (default 48 candidates, CTF_PLACEMENT_TRIES) and placement_gib (default 16: the cap
+ * on what the search may HOLD — it holds two buffers, the candidate and the best so far; CTF_PLACEMENT_GIB), tune_placement=False
+ * to switch it off; VecGridworldCtf.placement reports kind, ratio, candidates tried, bytes held and the time it took. */
 #define CTF_REVERSE_DEFAULT 0xFFFFFFFFu
 int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t reverse_mask, void* stream);
 /* which of the two a ctf_observe into obs_dev launches: 1 = k_observe_tiles, 0 = k_observe (profiling: attributing a measured

@@ -108,7 +108,7 @@ class VecGridworldCtf:
         self._tune_placement = bool(tune_placement)
         import os
 
-        self._placement_tries = int(placement_tries if placement_tries is not None else os.environ.get("CTF_PLACEMENT_TRIES", 8))
+        self._placement_tries = int(placement_tries if placement_tries is not None else os.environ.get("CTF_PLACEMENT_TRIES", 48))
         self._placement_gib = float(placement_gib if placement_gib is not None else os.environ.get("CTF_PLACEMENT_GIB", 16))
         self.placement_probe_ms = None
         self.placement_fill_ms = None
@@ -136,16 +136,21 @@ class VecGridworldCtf:
         return self._codes
 
     def _tune_obs_placement(self, good_enough=1.06):
-        """Keep the candidate allocation the render streams into fastest (see __init__); frees the others.
+        """Keep the candidate allocation the render streams into fastest (see __init__).
 
-        BOUNDED: at most ``placement_tries`` candidates (default 8; ctor argument or CTF_PLACEMENT_TRIES) and never more than
-        ``placement_gib`` GiB of them at once (default 16; CTF_PLACEMENT_GIB) nor 45 % of the free device memory — a
-        co-resident policy / learner is not starved while this searches, and an allocation failure just ends the search.
-        All candidates are held until the end (a freed one would simply be handed out again).
+        BOUNDED in what it HOLDS: one candidate beside the best one so far — two observation buffers, 3.3 GB for the arena batch —
+        never more than ``placement_gib`` GiB (default 16; CTF_PLACEMENT_GIB; a batch whose two buffers exceed it is not searched)
+        nor 45 % of the free device memory: a co-resident policy / learner is not starved while this searches.  A rejected candidate
+        goes back to the driver at once (``torch.cuda.empty_cache``); the next allocation is of an independent kind even when nothing
+        is held in between (tools/placement_probe2.py, profiles/r03_placement_search_strategies.txt: holding the rejected ones, as
+        round 2 did, finds fast buffers no more often), so the search can afford ``placement_tries`` candidates (default 48;
+        CTF_PLACEMENT_TRIES) at a few milliseconds each.  An allocation failure ends the search with what it has.
 
         A candidate is good enough when the render into it takes at most ``good_enough`` x the time of a plain ``fill_`` of
         the same buffer (which does not depend on the buffer's kind): 1.04-1.07 for the best buffers seen, 1.08-1.12 for an
         intermediate kind, 1.2-1.3 for the slow one.  ``self.placement`` says what was found."""
+        import time
+
         torch = _torch()
         stream = torch.cuda.current_stream(self.device)
 
@@ -163,15 +168,15 @@ class VecGridworldCtf:
             self.obs = buf
             return timed(lambda: self.observe(meta=False))
 
+        t0 = time.perf_counter()
         best = self.obs
         nbytes = max(1, best.numel())
         free_bytes, _ = torch.cuda.mem_get_info(self.device)
-        budget = min(int(self._placement_gib * (1 << 30)), int(0.45 * free_bytes))
-        tries = max(1, min(int(self._placement_tries), 1 + budget // nbytes))
-        best_ms, times = probe(best), []
-        times.append(best_ms)
+        budget = min(int(self._placement_gib * (1 << 30)), int(0.45 * free_bytes) + nbytes)  # (the first buffer is already ours)
+        tries = max(1, int(self._placement_tries)) if 2 * nbytes <= budget else 1
+        best_ms = probe(best)
+        times = [best_ms]
         fill_ms = timed(lambda: best.fill_(0))
-        candidates, cand = [best], None  # rejected candidates stay allocated until the end, so that new ones land elsewhere
         for _ in range(tries - 1):
             if best_ms <= good_enough * fill_ms:
                 break
@@ -179,11 +184,13 @@ class VecGridworldCtf:
                 cand = torch.empty_like(best)
             except torch.cuda.OutOfMemoryError:
                 break  # (fragmentation, another process on the GPU): the best one so far is kept
-            candidates.append(cand)
             ms = probe(cand)
             times.append(ms)
             if ms < best_ms:
                 best, best_ms = cand, ms
+            self.obs = best
+            del cand
+            torch.cuda.empty_cache()  # the loser goes back to the driver now, not into torch's cache
         self.obs = best
         fill_ms = timed(lambda: best.fill_(0))  # of the buffer that is kept
         ratio = best_ms / fill_ms
@@ -191,11 +198,8 @@ class VecGridworldCtf:
         self.placement_fill_ms = fill_ms
         self.placement = dict(kind="fast" if ratio <= 1.07 else ("intermediate" if ratio <= 1.14 else "slow"), render_over_fill=ratio,
                               render_ms=best_ms, fill_ms=fill_ms, candidates=len(times), slowest_candidate_render_ms=max(times),
-                              searched_bytes=len(times) * nbytes)
-        n_held = len(candidates)
-        del candidates, cand
-        if n_held > 4:
-            torch.cuda.empty_cache()  # the rejected candidates go back to the driver instead of sitting in torch's cache
+                              peak_held_bytes=min(len(times), 2) * nbytes, searched_bytes=len(times) * nbytes,
+                              search_ms=(time.perf_counter() - t0) * 1e3)
 
     # -- plumbing -----------------------------------------------------------------------------
     def _stream(self):

@@ -68,6 +68,12 @@ class BatchedRolloutCollector:
         self.dones = torch.zeros((S, E), dtype=torch.float32, device=dev)
         self.values = torch.zeros((S, E), dtype=torch.float32, device=dev)
         self._env_actions = torch.zeros((E, n), dtype=torch.int8, device=dev)
+        # compact mode with two distinct native networks, OFF by default: the opponent's conv front on a second stream beside the
+        # trained team's fc1 GEMM + head.  Identical results (tested), but measured slower — 22.6 M against 25.0 M env-steps/s at
+        # 65 536 envs: the front writes and the GEMM reads the same 2.2 GB per team at once and the front at one wave per SIMD does not
+        # tolerate co-resident waves (profiles/r03_policy_roofline.md)
+        self.overlap_teams = False
+        self._side_stream = None
 
     def use_codes(self, agent, opponent):
         if self.compact is None:
@@ -101,6 +107,34 @@ class BatchedRolloutCollector:
             md = (meta[:, sl] if sl is not None else meta.index_select(1, idx)).transpose(0, 1)
         return action.reshape(k, E), logprob.reshape(k, E), value.reshape(k, E), grid, md, mask.reshape(k, E)
 
+    def _two_teams_overlapped(self, agent, opponent, codes, meta):
+        """_policy_codes for both teams with the opponent's kernels on a side stream, started when the trained team's conv front is
+        through: its front then runs beside the trained team's fc1 GEMM and head.  Same kernels on the same inputs as the
+        one-stream order (each network keeps its own sampler offset): the results are identical."""
+        torch, vec = self.torch, self.vec
+        E, dev = vec.n_envs, codes.device
+        main = torch.cuda.current_stream(dev)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side = self._side_stream
+        one_team = lambda agents: len({vec.AGENT_TEAMS[i] for i in agents}) == 1
+        mask_a = self.mask_flag.index_select(0, self.trained_idx)[:, None].expand(-1, E).reshape(-1)
+        mask_o = self.mask_flag.index_select(0, self.others_idx)[:, None].expand(-1, E).reshape(-1).contiguous()
+        feats_a = agent._features_tuned(codes, meta, self.trained, one_team(self.trained), vec.self_cells)
+        side.wait_stream(main)  # codes, metadata and mask are there, and the trained team's front has had the chip to itself
+        with torch.cuda.stream(side):
+            feats_o = opponent._features_tuned(codes, meta, self.others, one_team(self.others), vec.self_cells)
+            o_act = opponent._tail(feats_o, mask=mask_o)[0]
+        action, logprob, _, value, _ = agent._tail(feats_a, mask=mask_a)
+        main.wait_stream(side)
+        o_act.record_stream(main)
+        k = len(self.trained)
+        sl = self._as_slice(self.trained)
+        grid = (codes[:, sl] if sl is not None else codes.index_select(1, self.trained_idx)).transpose(0, 1)
+        md = (meta[:, sl] if sl is not None else meta.index_select(1, self.trained_idx)).transpose(0, 1)
+        return ((action.reshape(k, E), logprob.reshape(k, E), value.reshape(k, E), grid, md, mask_a.reshape(k, E)),
+                o_act.reshape(len(self.others), E))
+
     @staticmethod
     def _as_slice(v):
         if len(v) == 1:
@@ -116,8 +150,12 @@ class BatchedRolloutCollector:
         torch, vec = self.torch, self.vec
         if use_codes:
             codes, meta = vec.observe_codes()  # default reversal: team(i) == 1
-            trained = self._policy_codes(agent, codes, meta, self.trained_idx, self.trained)
-            o_act = self._policy_codes(opponent, codes, meta, self.others_idx, self.others, want_inputs=False)[0]
+            if (self.overlap_teams and agent is not opponent and codes.is_cuda and hasattr(agent, "_features_tuned")
+                    and hasattr(opponent, "_features_tuned")):
+                trained, o_act = self._two_teams_overlapped(agent, opponent, codes, meta)
+            else:
+                trained = self._policy_codes(agent, codes, meta, self.trained_idx, self.trained)
+                o_act = self._policy_codes(opponent, codes, meta, self.others_idx, self.others, want_inputs=False)[0]
         else:
             obs, meta = vec.observe()
             trained = self._policy(agent, obs, meta, self.trained_idx)

@@ -436,3 +436,25 @@ def test_rollout_and_duel_with_the_native_policy_run_end_to_end():
     res = duel.batched_duel(vec, a, b, max_steps=40)
     assert res["steps"] == 41 and res["metrics"].shape == (512, 13, 8) and vec.status() == 0
     vec.close()
+
+
+def test_overlapping_the_two_teams_policy_kernels_changes_no_result():
+    """BatchedRolloutCollector in compact mode runs the opponent's conv front on a side stream beside the trained team's fc1 GEMM
+    and head (rollout._two_teams_overlapped): every tensor of the rollout equals the one-stream order's, bit for bit."""
+    rollout = importlib.import_module("marl-ctf-development_amd.rollout")
+    kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+    outs = []
+    for overlap in (False, True):
+        vec = pkg.VecGridworldCtf(3000, device=0, **kw)
+        torch.manual_seed(11)
+        a = fill_(native.CtfPolicyNative(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN, seed=101)).cuda()
+        b = fill_(native.CtfPolicyNative(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN, seed=202)).cuda()
+        col = rollout.BatchedRolloutCollector(vec, 12, 0)
+        col.overlap_teams = overlap
+        out = col.collect(a, b)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in out.items()})
+        assert vec.status() == 0
+        vec.close()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
