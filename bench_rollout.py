@@ -67,7 +67,7 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         micro = min(micro_batch, samples // num_minibatches)
         # A minibatch is evaluated in pieces (learner.optimise(micro_batch=): the same update, gradients accumulated).  MIOpen
         # compiles its convolution kernels on first use of every (batch, C, H, W) shape (up to a minute on a fresh box), so the
-        # warm-up runs one such piece untimed.  Pieces of 262 144 samples: 11.4 M sample-passes/s against 9.5 M at 65 536
+        # warm-up runs one such piece untimed.  Pieces of 262 144 samples: 14.9 M sample-passes/s against 11 M at 65 536
         # (tools/learner_breakdown.py; 13 GB of activations)
         log(f"rollout {rollout_s:.3f} s; warm-up piece of {micro} samples (MIOpen compiles its kernels) ...")
         throwaway = learner.PPOLearner(copy.deepcopy(nets[0]), vec.N_CHANNELS, update_epochs=1, num_minibatches=1)
@@ -81,7 +81,7 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         lrn = learner.PPOLearner(nets[0], vec.N_CHANNELS, update_epochs=update_epochs, num_minibatches=num_minibatches)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        losses = lrn.update(out, micro_batch=micro, progress=log)
+        losses = lrn.update(out, micro_batch=micro)  # (no progress callback: it would read the losses back after every minibatch)
         torch.cuda.synchronize()
         update_s = time.perf_counter() - t2
         res.update({
@@ -90,8 +90,8 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
             "value": envs * steps / (rollout_s + update_s), "learner_share_of_time": update_s / (rollout_s + update_s),
             "losses_v_pg_entropy": [float(x) for x in losses],
             "note": "the learner is the reference's PPO update (ppo.py:174-242) on the compact rollout: the native conv front as the forward "
-                    "(ctf_policy_features_train), fused tanh' + bias-gradient kernels, MIOpen's channels-last weight / data gradients, "
-                    "hipBLASLt GEMMs (policy_native._NativeFront); it still dominates the iteration",
+                    "(ctf_policy_features_train), a fused native data-gradient kernel (ctf_policy_front_dgrad), MIOpen's channels-last weight "
+                    "gradients, hipBLASLt GEMMs (policy_native._NativeFront); it still dominates the iteration",
         })
     else:
         res["value"] = res["rollout_env_steps_per_s"]

@@ -200,7 +200,7 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  * of > 1 GiB in ten is of a kind this launch streams into at 0.82 of the HBM peak, the others cost it 15-20 % — a property of the
  * allocation's physical backing, independent from one allocation to the next even after a free.  A caller that cares allocates a
  * candidate, times ctf_observe into it against a plain fill of the same bytes (the fill does not depend on the kind: render / fill
- * <= 1.07 is the fast kind), frees it if it is slow and tries again.  The Python facade does exactly that on first use of its
+ * <= 1.10 is the fast kind, >= 1.2 the slow one), frees it if it is slow and tries again.  The Python facade does exactly that on first use of its
  * observation buffer: knobs placement_tries (default 48 candidates, CTF_PLACEMENT_TRIES) and placement_gib (default 16: the cap
  * on what the search may HOLD — it holds two buffers, the candidate and the best so far; CTF_PLACEMENT_GIB), tune_placement=False
  * to switch it off; VecGridworldCtf.placement reports kind, ratio, candidates tried, bytes held and the time it took. */

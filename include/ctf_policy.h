@@ -79,6 +79,18 @@ int ctf_policy_tanh_grad(const uint16_t* grad_dev, const uint16_t* act_dev, uint
 int ctf_policy_act_grad_rows(const uint16_t* d_act_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_samples,
                              int32_t grid_size, int32_t meta_len, float* bias_grad_dev, void* stream);
 
+/* The whole data path of that backward in one launch (grid_size 11 / 15): dz2 = d_act * (1 - act^2) out channels-last, conv2's data
+ * gradient by MFMA on it, dz1 = that * (1 - h1^2) out channels-last, both bias gradients — what is left to a library are the two
+ * weight gradients (of conv2 from h1 and dz2, of conv1 from h0 and dz1).
+ *   d_act_dev, act_dev   bf16 [n_samples][ctf_policy_act_stride()]
+ *   h1_dev               bf16 [n_samples][(G-2)^2][16] as ctf_policy_features_train wrote it
+ *   conv2_t_frag_dev     bf16 [9][64][8]: [tap][lane][j] = conv2.weight[out = 8 * (lane >> 4) + j][in = lane & 15][tap], UNscaled
+ *   dz2_dev              bf16 [n_samples][(G-4)^2][32]        dz1_dev   bf16 [n_samples][(G-2)^2][16]
+ *   bias2_grad_dev / bias1_grad_dev   NULL, or float [32] / [16]: += per-channel sums (the caller zeroes them) */
+int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t* act_dev, const uint16_t* h1_dev, const void* conv2_t_frag_dev,
+                           int64_t n_samples, int32_t grid_size, int32_t meta_len, uint16_t* dz2_dev, uint16_t* dz1_dev,
+                           float* bias2_grad_dev, float* bias1_grad_dev, int32_t device_id, void* stream);
+
 /* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
  *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)
  *   logits += (mask - 1) * 1e9 with mask = [1]*5 + [0]*(A-5) where the decision is 1, all ones otherwise

@@ -1038,6 +1038,177 @@ __global__ void __launch_bounds__(256) k_tanh_grad_rows(const uint16_t* __restri
     if (bias_grad) bias_grad_flush<8, 4>(acc, bias_grad);
 }
 
+// ---- the data path of the training front's backward in ONE kernel (grid_size 11 / 15): per sample
+//   dz2 = d_act * (1 - act^2)            rows of the activation matrix in; out channels-last [S][P2][32] (the weight gradient of conv2
+//                                        is the library's) and, zero-padded by two cells, into LDS as [4 channel octets][G x G][8]
+//   dh1 = conv2's data gradient           dh1[i][y][x] = sum over taps, o of W2[o][i][tap] * dz2[o][y - dy][x - dx]: 16x16x32 MFMAs, the
+//                                        transposed weights register-resident (A operand), a lane's B operand 8 consecutive o of one cell
+//   dz1 = dh1 * (1 - h1^2)               h1 = tanh(conv1) as the forward saved it; out channels-last [S][P1][16]
+// and the per-channel sums of dz2 / dz1 in float32 (both bias gradients).  One wave per sample at a time, 20 KB of LDS per wave.
+struct DgradArgs {
+    const uint16_t* d_act;   // bf16 [S][Kp]
+    const uint16_t* act;     // bf16 [S][Kp]
+    const uint16_t* h1;      // bf16 [S][P1][16]
+    const u32x4_t* w2t;      // [9][64]: [tap][lane][j] = W2[o = 8 (lane >> 4) + j][i = lane & 15][tap], bf16, unscaled
+    uint16_t* dz2;           // bf16 [S][P2][32]
+    uint16_t* dz1;           // bf16 [S][P1][16]
+    float* db2;              // float [32] += , or NULL
+    float* db1;              // float [16] += , or NULL
+    int64_t S;
+    int32_t Kp;
+    uint32_t inv_g1, inv_g2;
+};
+template <int TG>
+__global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
+    extern __shared__ uint32_t lds[];
+    constexpr int G = TG, G1 = G - 2, G2 = G - 4, GG = G * G, P1 = G1 * G1, P2 = G2 * G2, PP = ((P2 + 31) >> 5) << 5;
+    constexpr int ZB = 4 * GG * 16, H1A = (((P1 + 15) >> 4) << 4) * 16;  // bytes: the padded dz2 image (4 octet arrays), one half of h1
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), wpb = blockDim.x / WAVE;
+    uint8_t* zp = (uint8_t*)lds + wave * (ZB + 2 * H1A);
+    uint8_t* h1 = zp + ZB;
+    u32x4_t w2t[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) w2t[t] = a.w2t[t * WAVE + lane];
+    {   // the border of the padded image stays zero for the whole launch
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        for (int q = lane; q < 4 * GG; q += WAVE) ((u32x4_t*)zp)[q] = z;
+    }
+    const int n2 = lane & 31, hh = lane >> 5;   // dz2 pass: position within a 32-position tile, channel-quad parity
+    const int n1 = lane & 15, g1 = lane >> 4;   // data-gradient pass: position within a 16-position tile, octet of o / quad of i
+    float s2[16], s1[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) s2[r] = 0.0f;
+    for (int64_t s = (int64_t)blockIdx.x * wpb + wave; s < a.S; s += (int64_t)gridDim.x * wpb) {
+        // h1 of this sample: channels-last [P1][16] -> [2 halves][P1][8]
+        const uint8_t* hsrc = (const uint8_t*)(a.h1 + (size_t)s * P1 * 16);
+        for (int idx = lane; idx < 2 * P1; idx += WAVE) *(u32x4_t*)(h1 + (idx & 1) * H1A + (idx >> 1) * 16) = *(const u32x4_t*)(hsrc + (size_t)idx * 16);
+        const uint16_t* drow = a.d_act + (size_t)s * a.Kp;
+        const uint16_t* arow = a.act + (size_t)s * a.Kp;
+        uint16_t* z2out = a.dz2 + (size_t)s * P2 * 32;
+#pragma unroll
+        for (int t = 0; t < PP / 32; t++) {
+            const int pa = 32 * t + n2;
+            const bool ok = pa < P2;
+            const int pc = ok ? pa : P2 - 1;
+            const int y = (int)(((uint32_t)pc * a.inv_g2) >> 16), x = pc - y * G2;
+            uint8_t* cell = zp + ((y + 2) * G + (x + 2)) * 16 + hh * 8;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {  // channels 8 q + 4 hh .. + 3: octet q, its half hh
+                const size_t col = ((size_t)(2 * q + hh) * PP + pa) * 4;
+                const u32x2_t g = *(const u32x2_t*)(drow + col), h = *(const u32x2_t*)(arow + col);
+                float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                const u32x2_t o = {tanh_grad2(g[0], h[0], d0, d1), tanh_grad2(g[1], h[1], d2, d3)};
+                if (ok) {
+                    *(u32x2_t*)(cell + q * GG * 16) = o;
+                    *(u32x2_t*)(z2out + (size_t)pa * 32 + 8 * q + 4 * hh) = o;
+                    s2[4 * q] += d0; s2[4 * q + 1] += d1; s2[4 * q + 2] += d2; s2[4 * q + 3] += d3;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        uint16_t* z1out = a.dz1 + (size_t)s * P1 * 16;
+        constexpr int T1 = (P1 + 15) >> 4;
+#pragma unroll 1
+        for (int t = 0; t < T1; t++) {
+            const int p = 16 * t + n1, pc = p < P1 ? p : P1 - 1;
+            const int yy = (int)(((uint32_t)pc * a.inv_g1) >> 16), xx = pc - yy * G1;
+            const uint8_t* base = zp + g1 * GG * 16 + ((yy + 2) * G + (xx + 2)) * 16;
+            f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const u32x4_t b = *(const u32x4_t*)(base - ((tap / 3) * G + (tap % 3)) * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w2t[tap]), as_bf16x8(b), acc, 0, 0, 0);
+            }
+            const u32x2_t hv = *(const u32x2_t*)(h1 + (g1 >> 1) * H1A + pc * 16 + (g1 & 1) * 8);  // h1 channels 4 g1 .. + 3 of this position
+            float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            const u32x2_t o = {tanh_grad2(pack_bf16(acc[0], acc[1]), hv[0], d0, d1), tanh_grad2(pack_bf16(acc[2], acc[3]), hv[1], d2, d3)};
+            if (p < P1) {
+                *(u32x2_t*)(z1out + (size_t)p * 16 + 4 * g1) = o;
+                s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();  // the next sample rewrites both images
+    }
+    // bias gradients: lanes with the same hh (dz2: channel 8 q + 4 hh + r) / the same g1 (dz1: channel 4 g1 + r) hold the same channels
+    __syncthreads();  // every wave is through with its images: the block's dynamic LDS (>= 16 KB) is the reduction's scratch now
+    float* red = (float*)lds;
+    if (a.db2) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[r * 256 + threadIdx.x] = s2[r];
+        __syncthreads();
+        if (threadIdx.x < 32) {  // channel c = 8 q + 4 hh + r2  <->  (r = 4 q + r2, hh)
+            const int c = threadIdx.x, q = c >> 3, h2 = (c >> 2) & 1, r = 4 * q + (c & 3);
+            float t = 0.0f;
+            for (int k = 0; k < 256; k++)
+                if (((k & 63) >> 5) == h2) t += red[r * 256 + k];
+            atomicAdd(a.db2 + c, t);
+        }
+        __syncthreads();
+    }
+    if (a.db1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[r * 256 + threadIdx.x] = s1[r];
+        __syncthreads();
+        if (threadIdx.x < 16) {  // channel c = 4 g1 + r
+            const int c = threadIdx.x, gg = c >> 2, r = c & 3;
+            float t = 0.0f;
+            for (int k = 0; k < 256; k++)
+                if (((k & 63) >> 4) == gg) t += red[r * 256 + k];
+            atomicAdd(a.db1 + c, t);
+        }
+    }
+}
+
+extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t* act_dev, const uint16_t* h1_dev, const void* conv2_t_frag_dev,
+                                      int64_t n_samples, int32_t grid_size, int32_t meta_len, uint16_t* dz2_dev, uint16_t* dz1_dev,
+                                      float* bias2_grad_dev, float* bias1_grad_dev, int32_t device_id, void* stream) {
+    if (!d_act_dev || !act_dev || !h1_dev || !conv2_t_frag_dev || !dz2_dev || !dz1_dev) return pfail("null argument");
+    if (grid_size != 15 && grid_size != 11) return pfail("the training front is built for grid_size 11 and 15 (the reference's maps)");
+    if (n_samples < 0) return pfail("n_samples out of range");
+    if (((uintptr_t)d_act_dev | (uintptr_t)act_dev | (uintptr_t)dz2_dev | (uintptr_t)dz1_dev) & 7) return pfail("8-byte alignment");
+    if (((uintptr_t)h1_dev | (uintptr_t)conv2_t_frag_dev) & 15) return pfail("h1_dev / conv2_t_frag_dev must be 16-byte aligned");
+    if (!n_samples) return 0;
+    DgradArgs a;
+    a.d_act = d_act_dev; a.act = act_dev; a.h1 = h1_dev; a.w2t = (const u32x4_t*)conv2_t_frag_dev; a.dz2 = dz2_dev; a.dz1 = dz1_dev;
+    a.db2 = bias2_grad_dev; a.db1 = bias1_grad_dev; a.S = n_samples; a.Kp = ctf_policy_act_stride(grid_size, meta_len);
+    const int G1 = grid_size - 2, G2 = grid_size - 4;
+    a.inv_g1 = (65536 + G1 - 1) / G1;
+    a.inv_g2 = (65536 + G2 - 1) / G2;
+    for (int p = 0; p < G1 * G1; p++)
+        if ((int)(((uint32_t)p * a.inv_g1) >> 16) != p / G1) return pfail("internal: reciprocal of G-2 not exact");
+    for (int p = 0; p < G2 * G2; p++)
+        if ((int)(((uint32_t)p * a.inv_g2) >> 16) != p / G2) return pfail("internal: reciprocal of G-4 not exact");
+    const int n_cus = policy_n_cus(device_id);
+    if (!n_cus) return pfail("hipGetDeviceProperties failed");
+    int dev_prev = 0;
+    if (hipGetDevice(&dev_prev) != hipSuccess) return pfail("hipGetDevice failed");
+    if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
+    const int wpb = 4;
+    const int per_wave = 4 * grid_size * grid_size * 16 + 2 * ((((G1 * G1) + 15) >> 4) << 4) * 16;
+    const size_t sh = (size_t)wpb * per_wave;
+    int per_cu = (int)((160 * 1024) / sh);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    int64_t blocks = (n_samples + wpb - 1) / wpb;
+    if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipSuccess;
+    if (grid_size == 15) {
+        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) hipLaunchKernelGGL(k_policy_front_dgrad<15>, dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+    } else {
+        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) hipLaunchKernelGGL(k_policy_front_dgrad<11>, dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+    }
+    if (err == hipSuccess) err = hipGetLastError();
+    if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err != hipSuccess) return pfail(hipGetErrorString(err));
+    return 0;
+}
+
 extern "C" int ctf_policy_tanh_grad(const uint16_t* grad_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_elems, float* bias_grad_dev,
                                     void* stream) {
     if (!grad_dev || !act_dev || !out_dev) return pfail("null argument");

@@ -99,12 +99,13 @@ class PPOLearner:
         batch_size = b_logprobs.shape[0]
         minibatch_size = int(batch_size // a.num_minibatches)
         b_inds = np.arange(batch_size)
-        clipfracs = []
         v_loss = pg_loss = entropy_loss = approx_kl = None
+        stats = None
         for epoch in range(a.update_epochs):
             np.random.shuffle(b_inds)
+            inds_dev = torch.from_numpy(b_inds).to(b_logprobs.device)  # the epoch's order, uploaded once
             for start in range(0, batch_size, minibatch_size):
-                mb_all = torch.as_tensor(b_inds[start:start + minibatch_size], device=b_logprobs.device)
+                mb_all = inds_dev[start:start + minibatch_size]
                 n_mb = mb_all.numel()
                 mb_adv_all = b_advantages[mb_all]
                 if a.norm_adv:
@@ -136,12 +137,14 @@ class PPOLearner:
                     # loss = pg_loss - ent_coef * entropy_loss + v_loss * vf_coef with every term a mean over the minibatch
                     ((pg_sum - a.ent_coef * ent_sum + v_sum * a.vf_coef) / n_mb).backward()
                     sums += torch.stack([pg_sum.detach(), v_sum.detach(), ent_sum.detach(), kl_sum, clip_sum]).double()
-                pg_loss, v_loss, entropy_loss, approx_kl, clipfrac = (sums / n_mb).tolist()  # the minibatch's one host round trip
-                clipfracs += [clipfrac]
+                stats = sums / n_mb  # stays on the device: the host reads the numbers once per epoch (or per minibatch for `progress`)
                 nn.utils.clip_grad_norm_(agent.parameters(), a.max_grad_norm)
                 self.optimizer.step()
                 if progress is not None:
+                    pg_loss, v_loss, entropy_loss, approx_kl, _ = stats.tolist()
                     progress(f"epoch {epoch} minibatch at {start}: v {v_loss:.4g} pg {pg_loss:.4g} entropy {entropy_loss:.4g}")
+            if stats is not None:
+                pg_loss, v_loss, entropy_loss, approx_kl, _ = stats.tolist()  # of the epoch's last minibatch, as the reference keeps them
             if a.target_kl is not None and approx_kl > a.target_kl:
                 break
         return v_loss, pg_loss, entropy_loss

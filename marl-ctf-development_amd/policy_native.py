@@ -56,6 +56,17 @@ def conv_fragments(conv1_w, conv1_b, conv2_w, conv2_b):
     return f1, b1, f2, b2
 
 
+def conv2_transposed_fragments(conv2_w):
+    """conv2.weight [32, 16, 3, 3] (unscaled) -> the data-gradient kernel's A operands (ctf_policy_front_dgrad):
+    [tap][lane][j] = W2[out = 8 * (lane >> 4) + j][in = lane & 15][tap]."""
+    w2t = np.asarray(conv2_w, np.float32).reshape(32, 16, 9)
+    lane, j = np.arange(64), np.arange(8)
+    f = np.zeros((9, 64, 8), np.float32)
+    for tap in range(9):
+        f[tap] = w2t[8 * (lane >> 4)[:, None] + j[None, :], (lane & 15)[:, None], tap]
+    return f
+
+
 def act_column_order(grid_size, meta_len):
     """new column -> reference column of fc1's input (-1 = padding, zero weight): the kernel writes conv2 channel c,
     position p at ((c // 4) * PP + p) * 4 + c % 4 with PP = the positions rounded up to whole 32-position tiles (every
@@ -96,17 +107,39 @@ def tail_fragments(fc2_w, fc2_b, action_w, action_b, value_w, value_b):
     return f2, (np.asarray(fc2_b, np.float64) * _TWO_LOG2E).astype(np.float32), fh, bh
 
 
+def gather_maps(n_channels, n_actions):
+    """Every kernel-side weight layout above is a gather of the module's parameters (times a scale, with zero padding).  The index
+    maps — derived once by pushing integer-valued stand-ins through the very functions that define the layouts — let ``prepare()``
+    rebuild all of them on the device after every optimiser step without a host round trip.  -> dict name -> int64 array of indices
+    into the concatenation of that group's parameters (-1: a zero of the layout)."""
+    def stand_ins(shapes):
+        out, k = [], 1
+        for sh in shapes:
+            n = int(np.prod(sh))
+            out.append(np.arange(k, k + n, dtype=np.float64).reshape(sh))
+            k += n
+        return out
+
+    idx = lambda a, scale: np.rint(np.asarray(a, np.float64) / scale).astype(np.int64) - 1
+    f1, b1, f2, b2 = conv_fragments(*stand_ins([(16, n_channels, 3, 3), (16,), (32, 16, 3, 3), (32,)]))
+    t2, tb2, th, tbh = tail_fragments(*stand_ins([(128, 256), (128,), (n_actions, 128), (n_actions,), (1, 128), (1,)]))
+    f2t = conv2_transposed_fragments(stand_ins([(32, 16, 3, 3)])[0])
+    return dict(f1=idx(f1, _TWO_LOG2E), b1=idx(b1, _TWO_LOG2E), f2=idx(f2, _TWO_LOG2E), b2=idx(b2, _TWO_LOG2E),
+                t2=idx(t2, _TWO_LOG2E), tb2=idx(tb2, _TWO_LOG2E), th=idx(th, 1.0), tbh=idx(tbh, 1.0), f2t=idx(f2t, 1.0))
+
+
 class _NativeFront(torch.autograd.Function):
-    """conv1 -> tanh -> conv2 -> tanh -> flatten ++ metadata of a training step with the native kernel as the FORWARD
-    (ctf_policy_features_train: the activation row fc1 consumes, plus the one-hot image and tanh(conv1) channels-last) and the
-    library's convolution gradients on exactly those tensors as the backward.  MIOpen's forward convolutions, the table lookup of
-    the planes, two tanh kernels and the bias adds leave the learner's pass; its weight- and data-gradient kernels stay."""
+    """conv1 -> tanh -> conv2 -> tanh -> flatten ++ metadata of a training step with native kernels for everything but the two
+    weight gradients: the FORWARD is ctf_policy_features_train (the activation row fc1 consumes, plus the one-hot image and
+    tanh(conv1) channels-last); the BACKWARD's data path is ctf_policy_front_dgrad (tanh' of both layers, conv2's data gradient by
+    MFMA, both bias gradients, one launch), and the library's weight-gradient kernels take the channels-last tensors those two wrote."""
 
     @staticmethod
     def forward(ctx, net, codes, meta, w1, b1, w2, b2):
         act, h0, h1 = net.features_train(codes, meta)
         ctx.save_for_backward(act, h0, h1, w2)
         ctx.geom = (net.grid_size, int(w1.shape[1]), net.metadata_size, net._ready()["lib"])
+        ctx.f2t = net._ready()["f2t"]  # conv2's weights transposed into the data-gradient kernel's operand order (this step's values)
         return act
 
     @staticmethod
@@ -120,20 +153,17 @@ class _NativeFront(torch.autograd.Function):
         ptr = lambda t: C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         d_act = d_act.to(bf).contiguous()
-        # tanh' of conv2's output: rows of the activation matrix in, [B, G2, G2, 32] = channels-last memory of [B, 32, G2, G2] out
+        # one launch: tanh' of conv2's output (rows of the activation matrix in, channels-last out), conv2's data gradient, tanh' of
+        # conv1's output, both bias gradients in float32; the library is left with the two weight gradients
         dz2 = torch.empty((b, g2, g2, 32), dtype=bf, device=dev)
-        db = torch.zeros(48, dtype=torch.float32, device=dev)  # both bias gradients: summed by the two kernels, in float32
-        db2, db1 = db[:32], db[32:]
-        if lib.ctf_policy_act_grad_rows(ptr(d_act), ptr(act), ptr(dz2), b, g, m, ptr(db2), stream) != 0:
-            raise _abi.CtfLibraryError("ctf_policy_act_grad_rows: " + (lib.ctf_policy_last_error() or b"").decode())
-        dz2 = dz2.permute(0, 3, 1, 2)
-        h1i = h1.view(b, g1, g1, 16).permute(0, 3, 1, 2)
-        dh1, dw2, _ = conv_bwd(dz2, h1i, w2.to(bf).contiguous(memory_format=cl), [32], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, True, False])
-        dh1 = dh1.contiguous(memory_format=cl)
         dz1 = torch.empty((b, g1, g1, 16), dtype=bf, device=dev)
-        if lib.ctf_policy_tanh_grad(ptr(dh1), ptr(h1), ptr(dz1), dz1.numel(), ptr(db1), stream) != 0:
-            raise _abi.CtfLibraryError("ctf_policy_tanh_grad: " + (lib.ctf_policy_last_error() or b"").decode())
-        dz1 = dz1.permute(0, 3, 1, 2)
+        db = torch.zeros(48, dtype=torch.float32, device=dev)
+        db2, db1 = db[:32], db[32:]
+        if lib.ctf_policy_front_dgrad(ptr(d_act), ptr(act), ptr(h1), ptr(ctx.f2t), b, g, m, ptr(dz2), ptr(dz1), ptr(db2), ptr(db1), dev.index, stream) != 0:
+            raise _abi.CtfLibraryError("ctf_policy_front_dgrad: " + (lib.ctf_policy_last_error() or b"").decode())
+        dz2, dz1 = dz2.permute(0, 3, 1, 2), dz1.permute(0, 3, 1, 2)
+        h1i = h1.view(b, g1, g1, 16).permute(0, 3, 1, 2)
+        _, dw2, _ = conv_bwd(dz2, h1i, w2.to(bf).contiguous(memory_format=cl), [32], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
         h0i = h0.view(b, g, g, 16).permute(0, 3, 1, 2)
         w1_shape = torch.empty((16, 16, 3, 3), dtype=bf, device=act.device).contiguous(memory_format=cl)  # only its shape is used
         _, dw1, _ = conv_bwd(dz1, h0i, w1_shape, [16], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
@@ -147,6 +177,7 @@ class CtfPolicyNative(CtfPolicy):
         super().__init__(n_actions, n_channels, grid_size, metadata_size, compute_dtype=torch.bfloat16)
         self.grid_size, self.metadata_size, self.n_channels = grid_size, metadata_size, n_channels
         self._prep = None
+        self._maps = None          # device-side index maps of prepare(), built on first use
         # Philox key of the action sampler and its running offset.  The key is unique per INSTANCE: a default-constructed
         # module derives it from the state of torch's generator WITHOUT drawing from it (reproducible under torch.manual_seed,
         # different for every module built, and no later torch draw moves because a module was built or copied), and a
@@ -179,7 +210,7 @@ class CtfPolicyNative(CtfPolicy):
 
     def __getstate__(self):  # copies / pickles carry the parameters, not the kernel-side operands or device buffers
         d = dict(self.__dict__)
-        d["_prep"], d["_act_bufs"] = None, {}
+        d["_prep"], d["_act_bufs"], d["_maps"] = None, {}, None
         return d
 
     def __deepcopy__(self, memo):  # a COPY samples from its own stream (see __init__); a restored pickle keeps the original's
@@ -202,30 +233,44 @@ class CtfPolicyNative(CtfPolicy):
 
     # -- weights in the kernels' / the GEMM's layouts ----------------------------------------------
     def prepare(self):
+        """The kernel-side copies of the weights (MFMA operand fragments, scaled biases, fc1's permuted and scaled weight), rebuilt on
+        the device: gathers through index maps that are computed once (gather_maps), float64 products rounded to float32 and then to
+        bf16 exactly as the host-side definitions round them — no host round trip, so an optimiser step per minibatch costs the
+        learner no pipeline stall."""
         dev = self.conv1.weight.device
         if dev.type != "cuda":
             raise _abi.CtfLibraryError("CtfPolicyNative runs on a HIP device only (there is no CPU fallback)")
         lib = _abi.load_library()
-        with torch.no_grad():
-            cpu = lambda t: t.detach().float().cpu().numpy()
-            f1, b1, f2, b2 = conv_fragments(cpu(self.conv1.weight), cpu(self.conv1.bias), cpu(self.conv2.weight), cpu(self.conv2.bias))
-            t2, tb2, th, tbh = tail_fragments(cpu(self.fc2.weight), cpu(self.fc2.bias), cpu(self.action_head.weight),
-                                              cpu(self.action_head.bias), cpu(self.value_head.weight), cpu(self.value_head.bias))
-            bf = torch.bfloat16
+        if self._maps is None or self._maps["dev"] != dev:
             order = act_column_order(self.grid_size, self.metadata_size)
-            w = self.fc1.weight.float() * _TWO_LOG2E  # fc1's output only feeds a tanh: same scaling as the conv stages
-            fc1 = torch.zeros((w.shape[0], len(order)), dtype=torch.float32, device=dev)
-            keep = torch.from_numpy(order >= 0).to(dev)
-            fc1[:, keep] = w[:, torch.from_numpy(order[order >= 0]).to(dev)]
-            up = lambda a, dt=None: (torch.from_numpy(a).to(dev) if dt is None else torch.from_numpy(a).to(dev).to(dt)).contiguous()
-            self._prep = dict(
-                lib=lib, kp=len(order), stamp=self._stamp(),
-                f1=up(f1, bf), b1=up(b1), f2=up(f2, bf), b2=up(b2),
-                fc1_w=fc1.to(bf).contiguous(), fc1_b=(self.fc1.bias.float() * _TWO_LOG2E).to(bf),
-                t2=up(t2, bf), tb2=up(tb2), th=up(th, bf), tbh=up(tbh),
-                col_src=torch.from_numpy(np.maximum(order, 0)).to(dev), col_keep=keep.to(torch.float32),
-            )
+            maps = {k: torch.from_numpy(v).to(dev) for k, v in gather_maps(self.n_channels, self.n_actions).items()}
+            maps.update(dev=dev, kp=len(order), col_src=torch.from_numpy(np.maximum(order, 0)).to(dev),
+                        col_keep=torch.from_numpy((order >= 0).astype(np.float32)).to(dev))
             assert lib.ctf_policy_act_stride(self.grid_size, self.metadata_size) == len(order)
+            self._maps = maps
+        m = self._maps
+        with torch.no_grad():
+            bf = torch.bfloat16
+            flat = lambda *ps: torch.cat([q.detach().reshape(-1) for q in ps]).double()
+            conv = flat(self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+            tail = flat(self.fc2.weight, self.fc2.bias, self.action_head.weight, self.action_head.bias, self.value_head.weight, self.value_head.bias)
+            w2 = flat(self.conv2.weight)
+
+            def take(src, ix, scale, dt):  # float64 product -> float32 -> dt, as conv_fragments / tail_fragments define it
+                v = torch.where(ix >= 0, src[ix.clamp(min=0)] * scale, torch.zeros((), dtype=torch.float64, device=dev))
+                return v.to(torch.float32).to(dt).contiguous()
+
+            f32 = torch.float32
+            fc1 = (self.fc1.weight.float() * _TWO_LOG2E).index_select(1, m["col_src"]) * m["col_keep"]  # zero weight on the row's padding
+            self._prep = dict(
+                lib=lib, kp=m["kp"], stamp=self._stamp(),
+                f1=take(conv, m["f1"], _TWO_LOG2E, bf), b1=take(conv, m["b1"], _TWO_LOG2E, f32),
+                f2=take(conv, m["f2"], _TWO_LOG2E, bf), b2=take(conv, m["b2"], _TWO_LOG2E, f32),
+                fc1_w=fc1.to(bf).contiguous(), fc1_b=(self.fc1.bias.float() * _TWO_LOG2E).to(bf),
+                t2=take(tail, m["t2"], _TWO_LOG2E, bf), tb2=take(tail, m["tb2"], _TWO_LOG2E, f32),
+                th=take(tail, m["th"], 1.0, bf), tbh=take(tail, m["tbh"], 1.0, f32),
+                col_src=m["col_src"], col_keep=m["col_keep"], f2t=take(w2, m["f2t"], 1.0, bf),
+            )
         return self
 
     def _stamp(self):
@@ -307,10 +352,12 @@ class CtfPolicyNative(CtfPolicy):
             value, logits = self.value_head(x), self.action_head(x)
         return value.float(), logits.float()
 
-    def _features_tuned(self, codes, meta, agent_idx, shared_view, self_cells, tries=6, good_enough=0.9):
-        """features_from_codes into a persistent activation buffer.  About half of all >1 GiB allocations on this pool stream
-        ~20 % slower for both the kernel's stores and the GEMM's reads ("Allocation placement"): on first use a
-        few candidate buffers are timed with the real work (front kernel + fc1 GEMM) and a fast one is kept."""
+    def _features_tuned(self, codes, meta, agent_idx, shared_view, self_cells, tries=12, slow_over_fast=1.1):
+        """features_from_codes into a persistent activation buffer.  Large allocations on this pool come in two kinds — the slow one
+        costs both the kernel's stores and the GEMM's reads ~20 % — and the kind is independent from one allocation to
+        the next even after a free (tools/placement_probe2.py): on first use candidates are timed with the real work (front kernel + fc1
+        GEMM), a loser goes back to the driver at once (two buffers held at most), and the search stops as soon as it has seen both
+        kinds, keeping the fast one."""
         p = self._ready()
         rows = len(agent_idx) * int(codes.shape[0])
         key = (rows, p["kp"], codes.device.index)
@@ -330,15 +377,20 @@ class CtfPolicyNative(CtfPolicy):
             return a.elapsed_time(b) / 2
 
         new = lambda: torch.empty((rows, p["kp"]), dtype=torch.bfloat16, device=codes.device)
-        cands = [new()]
-        times = [probe(cands[0])] if rows * p["kp"] * 2 > (256 << 20) else [0.0]
-        while 0.0 < min(times) and len(cands) < tries and min(times) > good_enough * max(times):  # both kinds seen: stop
-            cands.append(new())  # rejected candidates stay allocated meanwhile, so that new ones land elsewhere
-            times.append(probe(cands[-1]))
-        buf = cands[times.index(min(times))]
+        buf = new()
+        times = [probe(buf)] if rows * p["kp"] * 2 > (256 << 20) else [0.0]
+        while 0.0 < min(times) and len(times) < tries and max(times) < slow_over_fast * min(times):  # until both kinds were seen
+            try:
+                cand = new()
+            except torch.cuda.OutOfMemoryError:
+                break
+            times.append(probe(cand))
+            if times[-1] < min(times[:-1]):
+                buf = cand
+            del cand
+            torch.cuda.empty_cache()
         self._act_bufs[key] = buf
         self.placement_probe_ms = times
-        del cands
         return self.features_from_codes(codes, meta, agent_idx, out=buf, shared_view=shared_view, self_cells=self_cells)
 
     def _tail(self, feats, mask=None, given=None, want_logits=False):

@@ -10,7 +10,7 @@ from torch.profiler import profile, ProfilerActivity
 import learner_breakdown as lb
 
 piece = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["planes", "codes"]
+variants = [v for v in sys.argv[2].split(",") if v != "none"] if len(sys.argv) > 2 else ["planes", "codes"]
 dev = torch.device("cuda", 0)
 b = lb.batch(piece, dev)
 for variant in variants:
@@ -38,3 +38,22 @@ for variant in variants:
         torch.cuda.synchronize()
     print(f"==== {variant}, piece {piece}: 5 forward + backward passes")
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=90))
+
+if os.environ.get("PROFILE_OPTIMISE"):
+    # the whole update (minibatch gathers, losses, clipping, Adam) around the network passes: one epoch over 4 x piece samples
+    import time
+    n = 4 * piece
+    b = lb.batch(n, dev)
+    torch.manual_seed(0)
+    net = lb.pkg.policy_native.CtfPolicyNative(9, lb.C, lb.G, lb.M).to(dev)
+    lrn = lb.learner.PPOLearner(net, lb.C, update_epochs=1, num_minibatches=4)
+    run = lambda: lrn.optimise(b["grids"], b["meta"], b["logp"], b["act"], b["mask"], b["adv"], b["ret"], b["val"], micro_batch=piece)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        run()
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(f"==== optimise: one epoch over {n} samples in pieces of {piece}: wall {wall * 1e3:.1f} ms")
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=90))
