@@ -59,7 +59,8 @@ int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* meta_dev, int3
  * them as they are:
  *   codes_dev   uint8 [n_samples][G][G]           meta_dev   binary16 bits [n_samples][meta_len]
  *   act_dev     bf16 [n_samples][ctf_policy_act_stride()]
- *   h0_dev      bf16 [n_samples][G*G][16]         the one-hot input image (planes C..15 zero)
+ *   h0_dev      bf16 [n_samples][G*G][16]         the one-hot input image (planes C..15 zero); NULL: not written (ctf_policy_front_wgrad
+ *                                                 builds it from the codes itself)
  *   h1_dev      bf16 [n_samples][(G-2)^2][16]     tanh(conv1)
  * all 16-byte aligned; grid_size 11 or 15. */
 int ctf_policy_features_train(const uint8_t* codes_dev, const uint16_t* meta_dev, int64_t n_samples, int32_t grid_size,
@@ -90,6 +91,14 @@ int ctf_policy_act_grad_rows(const uint16_t* d_act_dev, const uint16_t* act_dev,
 int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t* act_dev, const uint16_t* h1_dev, const void* conv2_t_frag_dev,
                            int64_t n_samples, int32_t grid_size, int32_t meta_len, uint16_t* dz2_dev, uint16_t* dz1_dev,
                            float* bias2_grad_dev, float* bias1_grad_dev, int32_t device_id, void* stream);
+
+/* ... and the two weight gradients, contraction over positions on the matrix cores (two launches):
+ *   dw2[o][i][tap] += sum over samples and conv2 output positions of dz2[o][y][x] * h1[i][y + dy][x + dx]          float [32][16][9]
+ *   dw1[o][c][tap] += sum over samples and conv1 output positions of dz1[o][y][x] * onehot(codes)[c][y + dy][x + dx]  float [16][16][9]
+ * (conv weight layout [out][in][ky][kx], in-channels padded to 16; the caller zeroes both).  dz2 / dz1 as ctf_policy_front_dgrad wrote
+ * them, h1 as ctf_policy_features_train did, codes_dev uint8 [n_samples][G][G]. */
+int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h1_dev, const uint16_t* dz1_dev, const uint8_t* codes_dev,
+                           int64_t n_samples, int32_t grid_size, float* dw2_dev, float* dw1_dev, int32_t device_id, void* stream);
 
 /* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
  *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        if (TRAIN) pol_store_image(h0, H0A, GG, a.h0_out + (size_t)s * GG * 16, lane);
+        if (TRAIN && a.h0_out) pol_store_image(h0, H0A, GG, a.h0_out + (size_t)s * GG * 16, lane);
 
         // ---- conv1 + tanh -> h1.  (Positions >= P1 of the last tile read past h0 into h1 — inside this wave's LDS — and
         // land in h1 rows >= P1, which nothing reads.)
@@ -1209,6 +1209,182 @@ extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t*
     return 0;
 }
 
+// ---- the two WEIGHT gradients of the training front, contraction over positions on the matrix cores (grid_size 11 / 15)
+//   dW2[o][i][tap] = sum over samples, conv2 output positions (y, x) of dz2[o][y][x] * h1[i][y + dy][x + dx]
+//   dW1[o][c][tap] = sum over samples, conv1 output positions (y, x) of dz1[o][y][x] * x0[c][y + dy][x + dx]      (x0: the one-hot image)
+// One 16x16x32 MFMA contracts 32 positions = two image rows of 16 columns (the columns past the row's end are zeros of the A operand).
+// Both operands must then be POSITION-contiguous per lane (8 consecutive x of one channel = one ds_read_b128), i.e. transposed against
+// the channels-last tensors the other kernels exchange; the wave transposes them into LDS with 2-byte stores:
+//   A  [m = out channel][row][16 cols]                      the gradient image, tap-independent, row `rows` and cols >= width zero
+//   B  [dx][n = in channel][row][16 cols]                   the activation image, three copies shifted left by dx = 0, 1, 2 so that the
+//                                                           16-byte reads of every tap are aligned; entry [dx][n][r][c] = img[n][r][c + dx]
+// Accumulators (one f32x4 tile per tap and 16 out channels) live in registers across all samples of the wave; at the end the block's
+// four waves are summed through LDS and added to the float32 result with one atomicAdd per element and block.
+struct WgradArgs {
+    const uint16_t* grad;    // bf16 channels-last [S][GO*GO][CO]: dz2 (CO = 32) or dz1 (CO = 16)
+    const uint16_t* img;     // bf16 channels-last [S][GI*GI][16]: h1, or NULL when the image is built from codes
+    const uint8_t* codes;    // uint8 [S][GI*GI] (conv1 only): the one-hot image's source
+    float* dw;               // float [CO][16][9] += (the caller zeroes it)
+    int64_t S;
+};
+// GO: side of the gradient image, GI = GO + 2: side of the activation image, CO: out channels (16 or 32)
+template <int GO, int CO, bool FROM_CODES>
+__global__ void __launch_bounds__(256) k_policy_front_wgrad(WgradArgs a) {
+    extern __shared__ uint32_t lds[];
+    constexpr int GI = GO + 2, PO = GO * GO, PI = GI * GI;
+    constexpr int RA = GO + 1 + (GO & 1 ? 0 : 1);      // rows of A: GO + at least one zero row, an even count
+    constexpr int KS = RA / 2;                          // K-steps (two rows each)
+    constexpr int RB = RA + 2;                          // rows of B read: up to RA - 1 + 2
+    constexpr int A_CH = RA * 32 + 16, B_CH = RB * 32;  // bytes per channel (A padded against bank conflicts of the transposing stores)
+    constexpr int A_BYTES = CO * A_CH, B_BYTES = 3 * 16 * B_CH;
+    constexpr int NH = CO / 16;                         // 16-channel halves of the out channels
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), wpb = blockDim.x / WAVE;
+    uint8_t* A = (uint8_t*)lds + wave * (A_BYTES + B_BYTES);
+    uint8_t* B = A + A_BYTES;
+    {   // zeros everywhere once: the A rows / columns past the image and whatever of B the shifted copies never write stay zero
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        for (int q = lane; q < (A_BYTES + B_BYTES) / 16; q += WAVE) ((u32x4_t*)A)[q] = z;
+    }
+    f32x4_t acc[9][NH];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int h = 0; h < NH; h++) acc[t][h] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+    const int mn = lane & 15, kg = lane >> 4;           // operand row / column, k-group: row parity kg >> 1, columns 8 (kg & 1) ..
+    const int a_off = mn * A_CH + (kg >> 1) * 32 + (kg & 1) * 16;
+    const int b_off = mn * B_CH + (kg >> 1) * 32 + (kg & 1) * 16;
+    for (int64_t s = (int64_t)blockIdx.x * wpb + wave; s < a.S; s += (int64_t)gridDim.x * wpb) {
+        // ---- A: the gradient image, channels-last [PO][CO] -> [CO][RA][16]
+        const u32x4_t* gsrc = (const u32x4_t*)(a.grad + (size_t)s * PO * CO);
+        for (int idx = lane; idx < PO * (CO / 8); idx += WAVE) {
+            const u32x4_t v = gsrc[idx];
+            const int pos = idx / (CO / 8), oct = idx - pos * (CO / 8);
+            const int y = pos / GO, x = pos - y * GO;
+            uint8_t* dst = A + (oct * 8) * A_CH + y * 32 + x * 2;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                *(uint16_t*)(dst + (2 * j) * A_CH) = (uint16_t)(v[j] & 0xFFFFu);
+                *(uint16_t*)(dst + (2 * j + 1) * A_CH) = (uint16_t)(v[j] >> 16);
+            }
+        }
+        // ---- B: the activation image, three copies shifted by dx
+        if (FROM_CODES) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            for (int q = lane; q < B_BYTES / 16; q += WAVE) ((u32x4_t*)B)[q] = z;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            const uint8_t* cp = a.codes + (size_t)s * PI;
+            for (int c = lane; c < PI; c += WAVE) {
+                const uint32_t code = cp[c];
+                const int y = c / GI, x = c - y * GI;
+                const uint32_t ch = code & 0x7Fu;
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    if (x - dx < 0) continue;
+                    uint8_t* dst = B + dx * 16 * B_CH + y * 32 + (x - dx) * 2;
+                    if (ch != 0 && ch < 16) *(uint16_t*)(dst + ch * B_CH) = 0x3F80;
+                    if (code >> 7) *(uint16_t*)(dst) = 0x3F80;
+                }
+            }
+        } else {
+            const u32x4_t* isrc = (const u32x4_t*)(a.img + (size_t)s * PI * 16);
+            for (int idx = lane; idx < PI * 2; idx += WAVE) {
+                const u32x4_t v = isrc[idx];
+                const int pos = idx >> 1, oct = idx & 1;
+                const int y = pos / GI, x = pos - y * GI;
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    if (x - dx < 0) continue;
+                    uint8_t* dst = B + (dx * 16 + oct * 8) * B_CH + y * 32 + (x - dx) * 2;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        *(uint16_t*)(dst + (2 * j) * B_CH) = (uint16_t)(v[j] & 0xFFFFu);
+                        *(uint16_t*)(dst + (2 * j + 1) * B_CH) = (uint16_t)(v[j] >> 16);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        // ---- contraction: K-step ks = gradient rows 2 ks, 2 ks + 1; tap (dy, dx) reads the activation rows + dy of copy dx
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ks++) {
+            u32x4_t av[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) av[h] = *(const u32x4_t*)(A + a_off + h * 16 * A_CH + ks * 64);
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const u32x4_t bv = *(const u32x4_t*)(B + b_off + (t % 3) * 16 * B_CH + (ks * 2 + t / 3) * 32);
+#pragma unroll
+                for (int h = 0; h < NH; h++) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[h]), as_bf16x8(bv), acc[t][h], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();  // the next sample rewrites both images
+    }
+    // ---- the block's four partial sums -> one; D tile: lane holds rows m = 4 (lane >> 4) + r of column n = lane & 15
+    __syncthreads();
+    float* red = (float*)lds;  // [wave][tap][CO][16]
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[((wave * 9 + t) * CO + 16 * h + 4 * kg + r) * 16 + mn] = acc[t][h][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * CO * 16; e += blockDim.x) {
+        float v = 0.0f;
+        for (int w = 0; w < wpb; w++) v += red[w * 9 * CO * 16 + e];
+        const int t = e / (CO * 16), oi = e - t * (CO * 16);
+        atomicAdd(a.dw + (size_t)oi * 9 + t, v);  // [out][in][tap]
+    }
+}
+
+extern "C" int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h1_dev, const uint16_t* dz1_dev, const uint8_t* codes_dev,
+                                      int64_t n_samples, int32_t grid_size, float* dw2_dev, float* dw1_dev, int32_t device_id, void* stream) {
+    if (!dz2_dev || !h1_dev || !dz1_dev || !codes_dev || !dw2_dev || !dw1_dev) return pfail("null argument");
+    if (grid_size != 15 && grid_size != 11) return pfail("the training front is built for grid_size 11 and 15 (the reference's maps)");
+    if (n_samples < 0) return pfail("n_samples out of range");
+    if (((uintptr_t)dz2_dev | (uintptr_t)h1_dev | (uintptr_t)dz1_dev) & 15) return pfail("16-byte alignment");
+    if (!n_samples) return 0;
+    const int n_cus = policy_n_cus(device_id);
+    if (!n_cus) return pfail("hipGetDeviceProperties failed");
+    int dev_prev = 0;
+    if (hipGetDevice(&dev_prev) != hipSuccess) return pfail("hipGetDevice failed");
+    if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipSuccess;
+    const int wpb = 4;
+    auto launch = [&](auto kernel, int go, int co, const WgradArgs& a) {
+        const int ra = go + 1 + ((go & 1) ? 0 : 1), rb = ra + 2;
+        size_t sh = (size_t)wpb * ((size_t)co * (ra * 32 + 16) + 3 * 16 * rb * 32);
+        const size_t red = (size_t)wpb * 9 * co * 16 * 4;
+        if (sh < red) sh = red;
+        int per_cu = (int)((160 * 1024) / sh);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 2) per_cu = 2;
+        int64_t blocks = (a.S + wpb - 1) / wpb;
+        if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
+        if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+    };
+    WgradArgs a2, a1;
+    a2.grad = dz2_dev; a2.img = h1_dev; a2.codes = nullptr; a2.dw = dw2_dev; a2.S = n_samples;
+    a1.grad = dz1_dev; a1.img = nullptr; a1.codes = codes_dev; a1.dw = dw1_dev; a1.S = n_samples;
+    if (grid_size == 15) {
+        launch(k_policy_front_wgrad<11, 32, false>, 11, 32, a2);
+        launch(k_policy_front_wgrad<13, 16, true>, 13, 16, a1);
+    } else {
+        launch(k_policy_front_wgrad<7, 32, false>, 7, 32, a2);
+        launch(k_policy_front_wgrad<9, 16, true>, 9, 16, a1);
+    }
+    if (err == hipSuccess) err = hipGetLastError();
+    if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err != hipSuccess) return pfail(hipGetErrorString(err));
+    return 0;
+}
+
 extern "C" int ctf_policy_tanh_grad(const uint16_t* grad_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_elems, float* bias_grad_dev,
                                     void* stream) {
     if (!grad_dev || !act_dev || !out_dev) return pfail("null argument");
@@ -1241,7 +1417,7 @@ extern "C" int ctf_policy_features_train(const uint8_t* codes_dev, const uint16_
                                          int32_t meta_len, const void* conv1_frag_dev, const float* conv1_bias_dev,
                                          const void* conv2_frag_dev, const float* conv2_bias_dev, uint16_t* act_dev, uint16_t* h0_dev,
                                          uint16_t* h1_dev, int32_t device_id, void* stream) {
-    if (!codes_dev || !meta_dev || !conv1_frag_dev || !conv1_bias_dev || !conv2_frag_dev || !conv2_bias_dev || !act_dev || !h0_dev || !h1_dev)
+    if (!codes_dev || !meta_dev || !conv1_frag_dev || !conv1_bias_dev || !conv2_frag_dev || !conv2_bias_dev || !act_dev || !h1_dev)
         return pfail("null argument");
     if (grid_size != 15 && grid_size != 11) return pfail("the training front is built for grid_size 11 and 15 (the reference's maps)");
     if (n_samples < 1 || n_samples > 0x7FFFFFFF) return pfail("n_samples out of range");

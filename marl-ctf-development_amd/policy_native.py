@@ -136,8 +136,9 @@ class _NativeFront(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, codes, meta, w1, b1, w2, b2):
-        act, h0, h1 = net.features_train(codes, meta)
-        ctx.save_for_backward(act, h0, h1, w2)
+        ctx.native_wgrad = bool(net.native_wgrad)
+        act, h0, h1 = net.features_train(codes, meta, want_h0=not ctx.native_wgrad)
+        ctx.save_for_backward(act, h0 if h0 is not None else codes, h1, w2)
         ctx.geom = (net.grid_size, int(w1.shape[1]), net.metadata_size, net._ready()["lib"])
         ctx.f2t = net._ready()["f2t"]  # conv2's weights transposed into the data-gradient kernel's operand order (this step's values)
         return act
@@ -161,6 +162,12 @@ class _NativeFront(torch.autograd.Function):
         db2, db1 = db[:32], db[32:]
         if lib.ctf_policy_front_dgrad(ptr(d_act), ptr(act), ptr(h1), ptr(ctx.f2t), b, g, m, ptr(dz2), ptr(dz1), ptr(db2), ptr(db1), dev.index, stream) != 0:
             raise _abi.CtfLibraryError("ctf_policy_front_dgrad: " + (lib.ctf_policy_last_error() or b"").decode())
+        if ctx.native_wgrad:  # both weight gradients on the matrix cores too (h0 here is the codes: the kernel builds the one-hot image itself)
+            dw = torch.zeros(32 * 16 * 9 + 16 * 16 * 9, dtype=torch.float32, device=dev)
+            dw2, dw1 = dw[:32 * 16 * 9], dw[32 * 16 * 9:]
+            if lib.ctf_policy_front_wgrad(ptr(dz2), ptr(h1), ptr(dz1), ptr(h0), b, g, ptr(dw2), ptr(dw1), dev.index, stream) != 0:
+                raise _abi.CtfLibraryError("ctf_policy_front_wgrad: " + (lib.ctf_policy_last_error() or b"").decode())
+            return None, None, None, dw1.view(16, 16, 3, 3)[:, :c_in].contiguous(), db1, dw2.view(32, 16, 3, 3), db2
         dz2, dz1 = dz2.permute(0, 3, 1, 2), dz1.permute(0, 3, 1, 2)
         h1i = h1.view(b, g1, g1, 16).permute(0, 3, 1, 2)
         _, dw2, _ = conv_bwd(dz2, h1i, w2.to(bf).contiguous(memory_format=cl), [32], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
@@ -172,6 +179,7 @@ class _NativeFront(torch.autograd.Function):
 
 class CtfPolicyNative(CtfPolicy):
     native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
+    native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
 
     def __init__(self, n_actions, n_channels, grid_size, metadata_size, seed=None):
         super().__init__(n_actions, n_channels, grid_size, metadata_size, compute_dtype=torch.bfloat16)
@@ -318,7 +326,7 @@ class CtfPolicyNative(CtfPolicy):
         return out
 
     # -- the forward of a training step ----------------------------------------------------------------
-    def features_train(self, codes, meta):
+    def features_train(self, codes, meta, want_h0=True):
         """codes uint8 [B, G, G], meta float16 [B, M] -> (activation rows bf16 [B, Kp] as features_from_codes writes them, the one-hot
         input image bf16 [B, G*G, 16], tanh(conv1) bf16 [B, (G-2)^2, 16]) — ctf_policy_features_train."""
         p = self._ready()
@@ -328,8 +336,8 @@ class CtfPolicyNative(CtfPolicy):
         if not (meta.is_cuda and meta.dtype == torch.float16 and meta.is_contiguous() and tuple(meta.shape) == (b, self.metadata_size)):
             raise ValueError("meta must be a contiguous float16 CUDA tensor [B, M]")
         new = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=codes.device)
-        act, h0, h1 = new(b, p["kp"]), new(b, g * g, 16), new(b, (g - 2) ** 2, 16)
-        ptr = lambda t: C.c_void_p(t.data_ptr())
+        act, h0, h1 = new(b, p["kp"]), (new(b, g * g, 16) if want_h0 else None), new(b, (g - 2) ** 2, 16)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         rc = p["lib"].ctf_policy_features_train(ptr(codes), ptr(meta), b, g, self.metadata_size, ptr(p["f1"]), ptr(p["b1"]), ptr(p["f2"]),
                                                 ptr(p["b2"]), ptr(act), ptr(h0), ptr(h1), codes.device.index,
                                                 C.c_void_p(torch.cuda.current_stream(codes.device).cuda_stream))
