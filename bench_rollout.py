@@ -90,8 +90,8 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
             "value": envs * steps / (rollout_s + update_s), "learner_share_of_time": update_s / (rollout_s + update_s),
             "losses_v_pg_entropy": [float(x) for x in losses],
             "note": "the learner is the reference's PPO update (ppo.py:174-242) on the compact rollout: the native conv front as the forward "
-                    "(ctf_policy_features_train), a fused native data-gradient kernel (ctf_policy_front_dgrad), MIOpen's channels-last weight "
-                    "gradients, hipBLASLt GEMMs (policy_native._NativeFront); it still dominates the iteration",
+                    "(ctf_policy_features_train), native data- and weight-gradient kernels (ctf_policy_front_dgrad / _wgrad), hipBLASLt GEMMs "
+                    "for the dense layers (policy_native._NativeFront); it still dominates the iteration",
         })
     else:
         res["value"] = res["rollout_env_steps_per_s"]

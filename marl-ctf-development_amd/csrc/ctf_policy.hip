@@ -1228,21 +1228,25 @@ struct WgradArgs {
     int64_t S;
 };
 // GO: side of the gradient image, GI = GO + 2: side of the activation image, CO: out channels (16 or 32)
+typedef uint32_t u32x4_a2_t __attribute__((ext_vector_type(4), aligned(2)));  // a 16-byte LDS read at a 2-byte aligned address
 template <int GO, int CO, bool FROM_CODES>
-__global__ void __launch_bounds__(256) k_policy_front_wgrad(WgradArgs a) {
+__global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
     extern __shared__ uint32_t lds[];
     constexpr int GI = GO + 2, PO = GO * GO, PI = GI * GI;
     constexpr int RA = GO + 1 + (GO & 1 ? 0 : 1);      // rows of A: GO + at least one zero row, an even count
     constexpr int KS = RA / 2;                          // K-steps (two rows each)
     constexpr int RB = RA + 2;                          // rows of B read: up to RA - 1 + 2
-    constexpr int A_CH = RA * 32 + 16, B_CH = RB * 32;  // bytes per channel (A padded against bank conflicts of the transposing stores)
-    constexpr int A_BYTES = CO * A_CH, B_BYTES = 3 * 16 * B_CH;
+    constexpr int A_CH = RA * 32 + 16, B_ROW = 48, B_CH = RB * B_ROW + 16;  // bytes: per channel of A (padded against bank conflicts of the
+                                                        // transposing stores), per row of B (24 columns: a tap's read starts at column <= 10)
+    constexpr int A_BYTES = CO * A_CH, B_BYTES = 16 * B_CH;
     constexpr int NH = CO / 16;                         // 16-channel halves of the out channels
+    constexpr int NPA = PO * (CO / 8), NA = (NPA + WAVE - 1) / WAVE;             // 16-byte pieces of the gradient image, per lane
+    constexpr int NPB = FROM_CODES ? PI : PI * 2, NB = (NPB + WAVE - 1) / WAVE;  // code bytes / 16-byte pieces of the activation image
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), wpb = blockDim.x / WAVE;
     uint8_t* A = (uint8_t*)lds + wave * (A_BYTES + B_BYTES);
     uint8_t* B = A + A_BYTES;
-    {   // zeros everywhere once: the A rows / columns past the image and whatever of B the shifted copies never write stay zero
+    {   // zeros everywhere once: the A rows / columns past the image and the B columns past a row's end stay zero
         const u32x4_t z = {0u, 0u, 0u, 0u};
         for (int q = lane; q < (A_BYTES + B_BYTES) / 16; q += WAVE) ((u32x4_t*)A)[q] = z;
     }
@@ -1253,61 +1257,82 @@ __global__ void __launch_bounds__(256) k_policy_front_wgrad(WgradArgs a) {
         for (int h = 0; h < NH; h++) acc[t][h] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
     const int mn = lane & 15, kg = lane >> 4;           // operand row / column, k-group: row parity kg >> 1, columns 8 (kg & 1) ..
     const int a_off = mn * A_CH + (kg >> 1) * 32 + (kg & 1) * 16;
-    const int b_off = mn * B_CH + (kg >> 1) * 32 + (kg & 1) * 16;
-    for (int64_t s = (int64_t)blockIdx.x * wpb + wave; s < a.S; s += (int64_t)gridDim.x * wpb) {
-        // ---- A: the gradient image, channels-last [PO][CO] -> [CO][RA][16]
+    const int b_off = mn * B_CH + (kg >> 1) * B_ROW + (kg & 1) * 16;
+    // the next sample's inputs travel while this one is contracted: a lane's pieces sit in registers across the MFMA section
+    u32x4_t ga[NA], gb[FROM_CODES ? 1 : NB];
+    uint32_t cb[FROM_CODES ? NB : 1];
+    const int64_t s0 = (int64_t)blockIdx.x * wpb + wave, stride = (int64_t)gridDim.x * wpb;
+    auto fetch = [&](int64_t s) {
         const u32x4_t* gsrc = (const u32x4_t*)(a.grad + (size_t)s * PO * CO);
-        for (int idx = lane; idx < PO * (CO / 8); idx += WAVE) {
-            const u32x4_t v = gsrc[idx];
-            const int pos = idx / (CO / 8), oct = idx - pos * (CO / 8);
-            const int y = pos / GO, x = pos - y * GO;
-            uint8_t* dst = A + (oct * 8) * A_CH + y * 32 + x * 2;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                *(uint16_t*)(dst + (2 * j) * A_CH) = (uint16_t)(v[j] & 0xFFFFu);
-                *(uint16_t*)(dst + (2 * j + 1) * A_CH) = (uint16_t)(v[j] >> 16);
+        for (int u = 0; u < NA; u++) ga[u] = gsrc[min(lane + WAVE * u, NPA - 1)];
+        if (FROM_CODES) {
+            const uint8_t* cp = a.codes + (size_t)s * PI;
+#pragma unroll
+            for (int u = 0; u < NB; u++) cb[u] = cp[min(lane + WAVE * u, NPB - 1)];
+        } else {
+            const u32x4_t* isrc = (const u32x4_t*)(a.img + (size_t)s * PI * 16);
+#pragma unroll
+            for (int u = 0; u < NB; u++) gb[u] = isrc[min(lane + WAVE * u, NPB - 1)];
+        }
+    };
+    if (s0 < a.S) fetch(s0);
+    for (int64_t s = s0; s < a.S; s += stride) {
+        // ---- A: the gradient image, channels-last [PO][CO] -> [CO][RA][16]
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            const int idx = lane + WAVE * u;
+            if (idx < NPA) {
+                const int pos = idx / (CO / 8), oct = idx - pos * (CO / 8);
+                const int y = pos / GO, x = pos - y * GO;
+                uint8_t* dst = A + (oct * 8) * A_CH + y * 32 + x * 2;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    *(uint16_t*)(dst + (2 * j) * A_CH) = (uint16_t)(ga[u][j] & 0xFFFFu);
+                    *(uint16_t*)(dst + (2 * j + 1) * A_CH) = (uint16_t)(ga[u][j] >> 16);
+                }
             }
         }
-        // ---- B: the activation image, three copies shifted by dx
+        // ---- B: the activation image [16 channels][RB rows][24 columns]
         if (FROM_CODES) {
             const u32x4_t z = {0u, 0u, 0u, 0u};
             for (int q = lane; q < B_BYTES / 16; q += WAVE) ((u32x4_t*)B)[q] = z;
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
-            const uint8_t* cp = a.codes + (size_t)s * PI;
-            for (int c = lane; c < PI; c += WAVE) {
-                const uint32_t code = cp[c];
-                const int y = c / GI, x = c - y * GI;
-                const uint32_t ch = code & 0x7Fu;
 #pragma unroll
-                for (int dx = 0; dx < 3; dx++) {
-                    if (x - dx < 0) continue;
-                    uint8_t* dst = B + dx * 16 * B_CH + y * 32 + (x - dx) * 2;
+            for (int u = 0; u < NB; u++) {
+                const int c = lane + WAVE * u;
+                if (c < NPB) {
+                    const uint32_t code = cb[u], ch = code & 0x7Fu;
+                    const int y = c / GI, x = c - y * GI;
+                    uint8_t* dst = B + y * B_ROW + x * 2;
                     if (ch != 0 && ch < 16) *(uint16_t*)(dst + ch * B_CH) = 0x3F80;
                     if (code >> 7) *(uint16_t*)(dst) = 0x3F80;
                 }
             }
         } else {
-            const u32x4_t* isrc = (const u32x4_t*)(a.img + (size_t)s * PI * 16);
-            for (int idx = lane; idx < PI * 2; idx += WAVE) {
-                const u32x4_t v = isrc[idx];
-                const int pos = idx >> 1, oct = idx & 1;
-                const int y = pos / GI, x = pos - y * GI;
 #pragma unroll
-                for (int dx = 0; dx < 3; dx++) {
-                    if (x - dx < 0) continue;
-                    uint8_t* dst = B + (dx * 16 + oct * 8) * B_CH + y * 32 + (x - dx) * 2;
+            for (int u = 0; u < NB; u++) {
+                const int idx = lane + WAVE * u;
+                if (idx < NPB) {
+                    const int pos = idx >> 1, oct = idx & 1;
+                    const int y = pos / GI, x = pos - y * GI;
+                    uint8_t* dst = B + (oct * 8) * B_CH + y * B_ROW + x * 2;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        *(uint16_t*)(dst + (2 * j) * B_CH) = (uint16_t)(v[j] & 0xFFFFu);
-                        *(uint16_t*)(dst + (2 * j + 1) * B_CH) = (uint16_t)(v[j] >> 16);
+                        *(uint16_t*)(dst + (2 * j) * B_CH) = (uint16_t)(gb[u][j] & 0xFFFFu);
+                        *(uint16_t*)(dst + (2 * j + 1) * B_CH) = (uint16_t)(gb[u][j] >> 16);
                     }
                 }
             }
         }
+        {   // every lane issues the same loads, also behind the last sample (it re-reads itself)
+            const int64_t sn = s + stride < a.S ? s + stride : s;
+            fetch(sn);
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        // ---- contraction: K-step ks = gradient rows 2 ks, 2 ks + 1; tap (dy, dx) reads the activation rows + dy of copy dx
+        // ---- contraction: K-step ks = gradient rows 2 ks, 2 ks + 1; tap (dy, dx) reads the activation rows + dy from column + dx on
 #pragma unroll 1
         for (int ks = 0; ks < KS; ks++) {
             u32x4_t av[NH];
@@ -1315,7 +1340,7 @@ __global__ void __launch_bounds__(256) k_policy_front_wgrad(WgradArgs a) {
             for (int h = 0; h < NH; h++) av[h] = *(const u32x4_t*)(A + a_off + h * 16 * A_CH + ks * 64);
 #pragma unroll
             for (int t = 0; t < 9; t++) {
-                const u32x4_t bv = *(const u32x4_t*)(B + b_off + (t % 3) * 16 * B_CH + (ks * 2 + t / 3) * 32);
+                const u32x4_t bv = *(const u32x4_a2_t*)(B + b_off + (ks * 2 + t / 3) * B_ROW + (t % 3) * 2);
 #pragma unroll
                 for (int h = 0; h < NH; h++) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[h]), as_bf16x8(bv), acc[t][h], 0, 0, 0);
             }
@@ -1323,7 +1348,7 @@ __global__ void __launch_bounds__(256) k_policy_front_wgrad(WgradArgs a) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();  // the next sample rewrites both images
     }
-    // ---- the block's four partial sums -> one; D tile: lane holds rows m = 4 (lane >> 4) + r of column n = lane & 15
+    // ---- the block's partial sums -> one; D tile: lane holds rows m = 4 (lane >> 4) + r of column n = lane & 15
     __syncthreads();
     float* red = (float*)lds;  // [wave][tap][CO][16]
 #pragma unroll
@@ -1355,15 +1380,15 @@ extern "C" int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h
     if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
-    const int wpb = 4;
+    const int wpb = 2;
     auto launch = [&](auto kernel, int go, int co, const WgradArgs& a) {
         const int ra = go + 1 + ((go & 1) ? 0 : 1), rb = ra + 2;
-        size_t sh = (size_t)wpb * ((size_t)co * (ra * 32 + 16) + 3 * 16 * rb * 32);
+        size_t sh = (size_t)wpb * ((size_t)co * (ra * 32 + 16) + 16 * ((size_t)rb * 48 + 16));
         const size_t red = (size_t)wpb * 9 * co * 16 * 4;
         if (sh < red) sh = red;
         int per_cu = (int)((160 * 1024) / sh);
         if (per_cu < 1) per_cu = 1;
-        if (per_cu > 2) per_cu = 2;
+        if (per_cu > 4) per_cu = 4;  // 8 waves per CU = 2 per SIMD
         int64_t blocks = (a.S + wpb - 1) / wpb;
         if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
         if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

@@ -17,8 +17,8 @@ from collections import defaultdict
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
-    return hits[0] if hits else None
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)  # a directory reused by a later run: the newest files count
+    return hits[-1] if hits else None
 
 
 def is_ours(name):
