@@ -68,18 +68,6 @@ int ctf_policy_features_train(const uint8_t* codes_dev, const uint16_t* meta_dev
                               const void* conv2_frag_dev, const float* conv2_bias_dev, uint16_t* act_dev, uint16_t* h0_dev,
                               uint16_t* h1_dev, int32_t device_id, void* stream);
 
-/* The element-wise steps of that front's backward pass, tanh'(x) * incoming gradient = g * (1 - h^2), one pass over memory each:
- *   ctf_policy_tanh_grad       grad, act, out: bf16 arrays of n_elems (whole 16-channel positions) in the same layout — tanh(conv1),
- *                              channels-last
- *   ctf_policy_act_grad_rows   d_act, act: bf16 [n_samples][ctf_policy_act_stride()] (the activation matrix and the gradient fc1 hands
- *                              back); out: bf16 [n_samples][(G-4)^2][32], channels-last — what a library's convolution gradients take
- *   bias_grad_dev              NULL, or float [16] / [32]: += the per-channel sums of `out` in float32 (the convolution's bias gradient;
- *                              the caller zeroes it) */
-int ctf_policy_tanh_grad(const uint16_t* grad_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_elems, float* bias_grad_dev,
-                         void* stream);
-int ctf_policy_act_grad_rows(const uint16_t* d_act_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_samples,
-                             int32_t grid_size, int32_t meta_len, float* bias_grad_dev, void* stream);
-
 /* The whole data path of that backward in one launch (grid_size 11 / 15): dz2 = d_act * (1 - act^2) out channels-last, conv2's data
  * gradient by MFMA on it, dz1 = that * (1 - h1^2) out channels-last, both bias gradients — what is left to a library are the two
  * weight gradients (of conv2 from h1 and dz2, of conv1 from h0 and dz1).

@@ -142,8 +142,6 @@ SYMBOLS = {
     "ctf_policy_features": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
                                       _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "ctf_policy_features_train": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
-    "ctf_policy_tanh_grad": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
-    "ctf_policy_act_grad_rows": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "ctf_policy_front_dgrad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "ctf_policy_front_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
     "ctf_policy_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P,

@@ -985,8 +985,7 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
     return 0;
 }
 
-// ---- the two element-wise steps of the training front's backward (tanh' * incoming gradient), one pass over memory each; both
-// also sum their output per channel — the convolution's bias gradient — so that no separate reduction pass reads it again
+// ---- tanh' * incoming gradient for two bf16 pairs (and their float32 values, for the bias-gradient sums)
 __device__ __forceinline__ uint32_t tanh_grad2(uint32_t g2, uint32_t h2, float& s0, float& s1) {  // two bf16 pairs -> g * (1 - h * h)
     const float g0 = __builtin_bit_cast(float, g2 << 16), g1 = __builtin_bit_cast(float, g2 & 0xFFFF0000u);
     const float h0 = __builtin_bit_cast(float, h2 << 16), h1 = __builtin_bit_cast(float, h2 & 0xFFFF0000u);
@@ -995,49 +994,6 @@ __device__ __forceinline__ uint32_t tanh_grad2(uint32_t g2, uint32_t h2, float& 
     s1 += r1;
     return pack_bf16(r0, r1);
 }
-// block-wide: lanes with the same (threadIdx.x % GROUPS) hold partial sums of the same NV channels -> one atomicAdd per channel
-template <int GROUPS, int NV>
-__device__ __forceinline__ void bias_grad_flush(const float* acc, float* bias_grad) {
-    __shared__ float part[256 * NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++) part[j * 256 + threadIdx.x] = acc[j];
-    __syncthreads();
-    if (threadIdx.x < GROUPS * NV) {
-        const int grp = threadIdx.x % GROUPS, j = threadIdx.x / GROUPS;
-        float t = 0.0f;
-        for (int k = grp; k < 256; k += GROUPS) t += part[j * 256 + k];
-        atomicAdd(bias_grad + grp * NV + j, t);
-    }
-}
-// out = g * (1 - h^2) over n16 16-byte groups of bf16, same layout in and out (tanh(conv1): gradient and activation are both
-// channels-last with 16 channels: group i holds channels 8 (i & 1) .. + 7); bias_grad float [16] += per-channel sums (or NULL)
-__global__ void __launch_bounds__(256) k_tanh_grad(const u32x4_t* __restrict__ g, const u32x4_t* __restrict__ h, u32x4_t* __restrict__ out, size_t n16,
-                                                   float* bias_grad) {
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {  // the stride is even: i & 1 is the thread's
-        const u32x4_t a = g[i], b = h[i];
-        out[i] = (u32x4_t){tanh_grad2(a[0], b[0], acc[0], acc[1]), tanh_grad2(a[1], b[1], acc[2], acc[3]), tanh_grad2(a[2], b[2], acc[4], acc[5]),
-                           tanh_grad2(a[3], b[3], acc[6], acc[7])};
-    }
-    if (bias_grad) bias_grad_flush<2, 8>(acc, bias_grad);
-}
-// tanh(conv2): gradient and activation arrive as rows of the activation matrix (column ((c / 4) * PP + p) * 4 + c % 4); the product
-// leaves channels-last, [S][P2][32].  Thread = (sample, position p, channel quad q): consecutive threads write consecutive 8 bytes
-// and read 8-byte pieces that are contiguous over 8 consecutive p of one q.  bias_grad float [32] += per-channel sums (or NULL).
-__global__ void __launch_bounds__(256) k_tanh_grad_rows(const uint16_t* __restrict__ d_act, const uint16_t* __restrict__ act, uint16_t* __restrict__ out,
-                                                        int64_t n_samples, int Kp, int PP, int P2, float* bias_grad) {
-    const int64_t total = n_samples * P2 * 8;
-    float acc[4] = {0, 0, 0, 0};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {  // i & 7 = q is the thread's
-        const int64_t s = i / (P2 * 8);
-        const int r = (int)(i - s * (P2 * 8)), p = r >> 3, q = r & 7;
-        const size_t src = (size_t)s * Kp + ((size_t)q * PP + p) * 4;
-        const u32x2_t a = *(const u32x2_t*)(d_act + src), b = *(const u32x2_t*)(act + src);
-        *(u32x2_t*)(out + (size_t)i * 4) = (u32x2_t){tanh_grad2(a[0], b[0], acc[0], acc[1]), tanh_grad2(a[1], b[1], acc[2], acc[3])};
-    }
-    if (bias_grad) bias_grad_flush<8, 4>(acc, bias_grad);
-}
-
 // ---- the data path of the training front's backward in ONE kernel (grid_size 11 / 15): per sample
 //   dz2 = d_act * (1 - act^2)            rows of the activation matrix in; out channels-last [S][P2][32] (the weight gradient of conv2
 //                                        is the library's) and, zero-padded by two cells, into LDS as [4 channel octets][G x G][8]
@@ -1408,34 +1364,6 @@ extern "C" int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
     if (err != hipSuccess) return pfail(hipGetErrorString(err));
     return 0;
-}
-
-extern "C" int ctf_policy_tanh_grad(const uint16_t* grad_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_elems, float* bias_grad_dev,
-                                    void* stream) {
-    if (!grad_dev || !act_dev || !out_dev) return pfail("null argument");
-    if (n_elems < 0 || (n_elems & 15)) return pfail("n_elems must be a multiple of 16 (whole 16-channel positions)");
-    if (((uintptr_t)grad_dev | (uintptr_t)act_dev | (uintptr_t)out_dev) & 15) return pfail("16-byte alignment");
-    if (!n_elems) return 0;
-    const size_t n16 = (size_t)n_elems / 8;
-    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 8192 ? (n16 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_tanh_grad, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)grad_dev, (const u32x4_t*)act_dev, (u32x4_t*)out_dev, n16,
-                       bias_grad_dev);
-    const hipError_t err = hipGetLastError();
-    return err == hipSuccess ? 0 : pfail(hipGetErrorString(err));
-}
-
-extern "C" int ctf_policy_act_grad_rows(const uint16_t* d_act_dev, const uint16_t* act_dev, uint16_t* out_dev, int64_t n_samples,
-                                        int32_t grid_size, int32_t meta_len, float* bias_grad_dev, void* stream) {
-    if (!d_act_dev || !act_dev || !out_dev) return pfail("null argument");
-    if (grid_size < 5 || grid_size > 32 || n_samples < 0) return pfail("grid_size / n_samples out of range");
-    if (((uintptr_t)d_act_dev | (uintptr_t)act_dev | (uintptr_t)out_dev) & 7) return pfail("8-byte alignment");
-    if (!n_samples) return 0;
-    const int P2 = (grid_size - 4) * (grid_size - 4), PP = ((P2 + 31) >> 5) << 5, Kp = ctf_policy_act_stride(grid_size, meta_len);
-    const int64_t total = n_samples * P2 * 8;
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_tanh_grad_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_act_dev, act_dev, out_dev, n_samples, Kp, PP, P2, bias_grad_dev);
-    const hipError_t err = hipGetLastError();
-    return err == hipSuccess ? 0 : pfail(hipGetErrorString(err));
 }
 
 extern "C" int ctf_policy_features_train(const uint8_t* codes_dev, const uint16_t* meta_dev, int64_t n_samples, int32_t grid_size,
