@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update_epochs=4, num_minibatches=4, device=0, micro_batch=262144):
+def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update_epochs=4, num_minibatches=4, device=0, micro_batch=1 << 20):
     """-> dict: rollout / update / total env-steps per second of one PPO iteration (rollout of `steps` env steps of `envs`
     envs, then `update_epochs` x `num_minibatches` minibatch updates over its envs * steps * 4 samples)."""
     import torch
@@ -67,8 +67,8 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         micro = min(micro_batch, samples // num_minibatches)
         # A minibatch is evaluated in pieces (learner.optimise(micro_batch=): the same update, gradients accumulated).  MIOpen
         # compiles its convolution kernels on first use of every (batch, C, H, W) shape (up to a minute on a fresh box), so the
-        # warm-up runs one such piece untimed.  Pieces of 262 144 samples: 14.9 M sample-passes/s against 11 M at 65 536
-        # (tools/learner_breakdown.py; 13 GB of activations)
+        # warm-up runs one such piece untimed.  In this iteration (65 536 envs x 16 steps: minibatches of 1 048 576 samples): 16.8 / 17.7 /
+        # 18.4 M sample-passes/s in pieces of 262 144 / 524 288 / the whole minibatch (36 GB of activations)
         log(f"rollout {rollout_s:.3f} s; warm-up piece of {micro} samples (MIOpen compiles its kernels) ...")
         throwaway = learner.PPOLearner(copy.deepcopy(nets[0]), vec.N_CHANNELS, update_epochs=1, num_minibatches=1)
         adv, ret = throwaway.advantages(out)
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--no-update", action="store_true", help="rollout only (round 1's figure)")
     ap.add_argument("--update-epochs", type=int, default=4)
     ap.add_argument("--num-minibatches", type=int, default=4)
-    ap.add_argument("--micro-batch", type=int, default=262144, help="samples per forward / backward piece of a minibatch")
+    ap.add_argument("--micro-batch", type=int, default=1 << 20, help="samples per forward / backward piece of a minibatch")
     args = ap.parse_args()
     print(json.dumps(run(args.envs, args.steps, args.policy, args.dtype, not args.no_update, args.update_epochs, args.num_minibatches, micro_batch=args.micro_batch)))
 
