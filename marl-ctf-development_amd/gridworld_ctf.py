@@ -108,7 +108,7 @@ class VecGridworldCtf:
         self._tune_placement = bool(tune_placement)
         import os
 
-        self._placement_tries = int(placement_tries if placement_tries is not None else os.environ.get("CTF_PLACEMENT_TRIES", 48))
+        self._placement_tries = int(placement_tries if placement_tries is not None else os.environ.get("CTF_PLACEMENT_TRIES", 128))
         self._placement_gib = float(placement_gib if placement_gib is not None else os.environ.get("CTF_PLACEMENT_GIB", 16))
         self.placement_probe_ms = None
         self.placement_fill_ms = None
@@ -143,7 +143,7 @@ class VecGridworldCtf:
         nor 45 % of the free device memory: a co-resident policy / learner is not starved while this searches.  A rejected candidate
         goes back to the driver at once (``torch.cuda.empty_cache``); the next allocation is of an independent kind even when nothing
         is held in between (tools/placement_probe2.py, profiles/r03_placement_search_strategies.txt: holding the rejected ones, as
-        round 2 did, finds fast buffers no more often), so the search can afford ``placement_tries`` candidates (default 48;
+        round 2 did, finds fast buffers no more often), so the search can afford ``placement_tries`` candidates (default 128;
         CTF_PLACEMENT_TRIES) at a few milliseconds each.  An allocation failure ends the search with what it has.
 
         The search stops at a candidate whose render takes at most ``good_enough`` x the time of a plain ``fill_`` of the same
