@@ -261,20 +261,37 @@ __device__ __forceinline__ void wave_next_block(int lane, const uint32_t* src, u
 // ring is linked to it (mirror, hit bit of its last position).  src / dst: 2 x 624 words of the wave's LDS.  `init`: the CURRENT
 // ring's digests are made too (after a seed or a state import).  2.5 KB read, 2.5 KB + the digests written, every access of the
 // wave contiguous.
-__device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p, int e, int stream, uint32_t flag, int lane, uint32_t* src,
-                                            uint32_t* dst, bool init) {
-    StreamFull st = stream_full(cfg, p, e, stream);
-    st.cur = ring_source(flag, p.rngpos[2 * (size_t)e + stream]);  // the flag says which ring is stale (the position word may be moving)
-    ring_counter_params(st.q, p, e, stream, st.cur);
-    const u32x4_t* gsrc = (const u32x4_t*)(st.r.raw + st.cur * CTF_MT_N);
-    u32x4_t* gdst = (u32x4_t*)(st.r.raw + (1 - st.cur) * CTF_MT_N);
+// the ring's words on their way into the wave (issued early: the previous ring of the same tail block is still being worked on)
+struct RingIn {
+    StreamFull st;
+    u32x4_t a, b, c;
+};
+__device__ __forceinline__ RingIn ring_fetch(const DevCfg& cfg, const DevPtrs& p, int e, int stream, uint32_t flag, int lane) {
+    RingIn in;
+    in.st.r = ring_ptrs(p, e, stream);
+    in.st.q = ring_params(cfg, p, e, stream);
+    // The flag says which ring is stale (the position word may be moving); only an init pass (flag 0) has to read the position word —
+    // the branch is uniform, and without it every regeneration would wait for that load before it can even address its ring: one
+    // more dependent memory round trip on a 5.65 us job.
+    const uint32_t uflag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);  // (the same in every lane: one ring per wave)
+    if (uflag >= 2u) in.st.cur = 1u - (uflag - 2u);
+    else in.st.cur = ring_source(uflag, p.rngpos[2 * (size_t)e + stream]);
+    ring_counter_params(in.st.q, p, e, stream, in.st.cur);
+    const u32x4_t* gsrc = (const u32x4_t*)(in.st.r.raw + in.st.cur * CTF_MT_N);
     constexpr int NQ = CTF_MT_N / 4;  // 156 quads: two full passes of the wave and 28 lanes of a third
-    {
-        const u32x4_t a = gsrc[lane], b = gsrc[lane + WAVE], c = gsrc[lane + 2 * WAVE < NQ ? lane + 2 * WAVE : 0];
-        ((u32x4_t*)src)[lane] = a;
-        ((u32x4_t*)src)[lane + WAVE] = b;
-        if (lane + 2 * WAVE < NQ) ((u32x4_t*)src)[lane + 2 * WAVE] = c;
-    }
+    in.a = gsrc[lane];
+    in.b = gsrc[lane + WAVE];
+    in.c = gsrc[lane + 2 * WAVE < NQ ? lane + 2 * WAVE : 0];
+    return in;
+}
+__device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p, int e, int stream, const RingIn& in, int lane, uint32_t* src,
+                                            uint32_t* dst, bool init) {
+    StreamFull st = in.st;
+    u32x4_t* gdst = (u32x4_t*)(st.r.raw + (1 - st.cur) * CTF_MT_N);
+    constexpr int NQ = CTF_MT_N / 4;
+    ((u32x4_t*)src)[lane] = in.a;
+    ((u32x4_t*)src)[lane + WAVE] = in.b;
+    if (lane + 2 * WAVE < NQ) ((u32x4_t*)src)[lane + 2 * WAVE] = in.c;
     RNG_WAVE_SYNC();
     wave_next_block(lane, src, dst, st.q);
     {   // the new block's raw words leave; both LDS copies then become OUTPUT words (of ring c only what is looked at)
@@ -359,11 +376,23 @@ __device__ __forceinline__ void tail_block(const DevCfg& cfg, const DevPtrs& p, 
     unsigned long long work = __ballot(flag >= 2u && (uint32_t)(((first + lane) >> 1) + (int)phase) % (uint32_t)spread == 0u);
     STEP_STAMP(0);
     int n_done = 0;
-    while (work) {  // uniform
-        const int k = __ffsll((long long)work) - 1;
+    if (work) {  // uniform
+        int k = __ffsll((long long)work) - 1;
         work &= work - 1;
-        refill_ring(cfg, p, (first + k) >> 1, (first + k) & 1, (uint32_t)__shfl((int)flag, k, WAVE), lane, lds, lds + CTF_MT_N, false);
-        n_done++;
+        RingIn cur = ring_fetch(cfg, p, (first + k) >> 1, (first + k) & 1, (uint32_t)__shfl((int)flag, k, WAVE), lane);
+        for (;;) {
+            // the next ring's words set out before this one is worked on (its loads land during the ~3 us of twisting and digesting)
+            const int kn = work ? __ffsll((long long)work) - 1 : k;
+            const bool more = work != 0;
+            work &= work - 1;
+            RingIn nxt = cur;
+            if (more) nxt = ring_fetch(cfg, p, (first + kn) >> 1, (first + kn) & 1, (uint32_t)__shfl((int)flag, kn, WAVE), lane);
+            refill_ring(cfg, p, (first + k) >> 1, (first + k) & 1, cur, lane, lds, lds + CTF_MT_N, false);
+            n_done++;
+            if (!more) break;
+            cur = nxt;
+            k = kn;
+        }
     }
     STEP_STAMP(4);
 #if STEP_TRACE
@@ -1204,7 +1233,7 @@ extern "C" __global__ void __launch_bounds__(256) k_rng_refill(DevCfg cfg, DevPt
         const int k = __ffsll((long long)work) - 1;
         work &= work - 1;
         const int t = first + k, e = e0 + (t >> 1), stream = t & 1;
-        refill_ring(cfg, p, e, stream, (uint32_t)__shfl((int)flag, k, WAVE), lane, src, dst, init != 0);
+        refill_ring(cfg, p, e, stream, ring_fetch(cfg, p, e, stream, (uint32_t)__shfl((int)flag, k, WAVE), lane), lane, src, dst, init != 0);
     }
 }
 
