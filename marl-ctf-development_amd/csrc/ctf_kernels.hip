@@ -261,6 +261,11 @@ __device__ __forceinline__ void wave_next_block(int lane, const uint32_t* src, u
 // ring is linked to it (mirror, hit bit of its last position).  src / dst: 2 x 624 words of the wave's LDS.  `init`: the CURRENT
 // ring's digests are made too (after a seed or a state import).  2.5 KB read, 2.5 KB + the digests written, every access of the
 // wave contiguous.
+#if STEP_TRACE
+#define RING_STAMP(k) CTF_STAMP(k)  // of a tail block's LAST ring (tools/trace_step.py)
+#else
+#define RING_STAMP(k) do { } while (0)
+#endif
 // the ring's words on their way into the wave (issued early: the previous ring of the same tail block is still being worked on)
 struct RingIn {
     StreamFull st;
@@ -292,8 +297,10 @@ __device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p,
     ((u32x4_t*)src)[lane] = in.a;
     ((u32x4_t*)src)[lane + WAVE] = in.b;
     if (lane + 2 * WAVE < NQ) ((u32x4_t*)src)[lane + 2 * WAVE] = in.c;
+    RING_STAMP(10);
     RNG_WAVE_SYNC();
     wave_next_block(lane, src, dst, st.q);
+    RING_STAMP(11);
     {   // the new block's raw words leave; both LDS copies then become OUTPUT words (of ring c only what is looked at)
         u32x4_t v[3];
 #pragma unroll
@@ -320,9 +327,12 @@ __device__ __forceinline__ void refill_ring(const DevCfg& cfg, const DevPtrs& p,
         }
     }
     RNG_WAVE_SYNC();
+    RING_STAMP(12);
     if (init) wave_digest(lane, src, st.r, (int)st.cur, st.q);
     wave_digest(lane, dst, st.r, 1 - (int)st.cur, st.q);
+    RING_STAMP(13);
     wave_link(lane, src, dst, st.r, (int)st.cur, st.q);
+    RING_STAMP(14);
     if (lane == 0) {
         ring_counter_store(st.q, p, e, stream, 1u - st.cur);
         p.rngready[2 * (size_t)e + stream] = 1;

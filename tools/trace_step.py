@@ -60,6 +60,11 @@ if full.shape[1] > nblk:  # the tail blocks (ring regeneration) that fit into th
     print("tail blocks traced: %d per step; rings per block mean %.2f max %d; start (us after the launch's first block) p10/p50/p90/max %s; end p50/p90/p99/max %s; "
           "life of a block with work: mean %.2f us, per ring %.2f us" % (tl.shape[1], nd.mean(), nd.max(), np.round(np.percentile(ts, [10, 50, 90, 100]), 1),
           np.round(np.percentile(te, [50, 90, 99, 100]), 1), (te - ts)[busy].mean(), ((te - ts)[busy] / nd[busy]).mean()))
+    one = nd == 1  # blocks with exactly one ring: its phases (stamps 0, 10..14, 4)
+    if one.any():
+        seq = [0, 10, 11, 12, 13, 14, 4]
+        lab = ["flags -> ring words in LDS", "twist (3 chunks)", "raw words out, tempering", "digests", "link (mirror)", "flag, end"]
+        print("one-ring tail blocks (%d): " % int(one.sum()) + "; ".join("%s %.2f us" % (lab[i], ((tl[:, :, seq[i + 1]] - tl[:, :, seq[i]]) / 100.0)[one].mean()) for i in range(6)))
 a = full[:, :nblk, :]
 print(f"{wl} {E} envs, {lanes} lanes per env, {nblk} blocks traced; k_step by HIP events (traced build): {np.mean(kms) * 1e3:.1f} us")
 t0 = a[:, :, 0].min(axis=1, keepdims=True)
