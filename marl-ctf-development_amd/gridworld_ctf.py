@@ -147,8 +147,8 @@ class VecGridworldCtf:
         CTF_PLACEMENT_TRIES) at a few milliseconds each.  An allocation failure ends the search with what it has.
 
         The search stops at a candidate whose render takes at most ``good_enough`` x the time of a plain ``fill_`` of the same
-        buffer (which does not depend on the buffer's kind), or as soon as it holds one that is 7 % faster than the slowest it has
-        seen — the kinds form two clusters (render / fill 1.05-1.12 and 1.20-1.27 over this round's boxes, the fill itself 0.234-0.243
+        buffer (which does not depend on the buffer's kind), or eight tries after it first holds one that is 7 % faster than the slowest
+        it has seen — the kinds form two clusters (render / fill 1.05-1.12 and 1.20-1.27 over this round's boxes, the fill itself 0.234-0.243
         ms from box to box), so that is "both kinds seen, the fast one in hand".  ``self.placement`` says what was found."""
         import time
 
@@ -178,9 +178,14 @@ class VecGridworldCtf:
         best_ms = probe(best)
         times = [best_ms]
         fill_ms = timed(lambda: best.fill_(0))
+        polish = 8  # once a buffer of the good cluster is in hand: a few more tries for its best members (0.253-0.266 ms on the arena)
         for _ in range(tries - 1):
-            if best_ms <= good_enough * fill_ms or best_ms <= 0.93 * max(times):
+            if best_ms <= good_enough * fill_ms:
                 break
+            if best_ms <= 0.93 * max(times):
+                if polish == 0:
+                    break
+                polish -= 1
             try:
                 cand = torch.empty_like(best)
             except torch.cuda.OutOfMemoryError:
