@@ -647,3 +647,35 @@ def test_one_hip_runtime_in_the_process():
     libs = {line.split()[-1] for line in maps_txt.splitlines() if "libamdhip64" in line}
     assert len(libs) == 1, libs
     assert any("libctf_hip.so" in line for line in maps_txt.splitlines())
+
+
+@pytest.mark.gpu
+def test_placement_search_is_bounded_and_says_what_it_found():
+    """VecGridworldCtf looks for an observation buffer of the fast kind on first use: it holds two buffers at most, tries no
+    more than it was told to, leaves the render's output identical, and reports kind / ratio / candidates / bytes / time."""
+    torch = pytest.importorskip("torch")
+    kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+    E = 16384  # 413 MB of observations: above the 256 MiB threshold of the default
+    ref = pkg.VecGridworldCtf(E, device=_dev(), tune_placement=False, **kw)
+    want, want_meta = ref.observe()
+    want = want.clone()
+    vec = pkg.VecGridworldCtf(E, device=_dev(), placement_tries=5, placement_gib=2, **kw)
+    assert vec.placement is None
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    got, got_meta = vec.observe()
+    pl = vec.placement
+    nbytes = got.numel()
+    assert set(pl) >= {"kind", "render_over_fill", "render_ms", "fill_ms", "candidates", "slowest_candidate_render_ms", "peak_held_bytes",
+                       "searched_bytes", "search_ms"}
+    assert 1 <= pl["candidates"] <= 5 and pl["kind"] in ("fast", "intermediate", "slow") and len(vec.placement_probe_ms) == pl["candidates"]
+    assert pl["peak_held_bytes"] <= 2 * nbytes and pl["searched_bytes"] == pl["candidates"] * nbytes
+    assert torch.cuda.max_memory_allocated() - base <= 2 * nbytes + (64 << 20)  # the candidate and the best so far, never more
+    assert pl["render_ms"] == min(vec.placement_probe_ms) and pl["slowest_candidate_render_ms"] == max(vec.placement_probe_ms)
+    assert torch.equal(got, want) and torch.equal(got_meta, want_meta)
+    # a cap below two buffers: no search at all
+    small = pkg.VecGridworldCtf(E, device=_dev(), placement_gib=0.5, **kw)
+    small.observe()
+    assert small.placement["candidates"] == 1
+    for v in (ref, vec, small):
+        v.close()
