@@ -1,0 +1,78 @@
+"""`bench.py --gpus N` / `bench_rollout.py --gpus N` must themselves start N ranks (the reference's N-worker launch is one Ray task
+per env, ppo.py:264-266,349-376).  Driven here without a GPU: CTF_BENCH_DRYRUN=1 runs everything of the bench but the kernels — the
+launcher, torchrun's rendezvous on 127.0.0.1, the process group (gloo), the barrier, the max-over-ranks rule, the self-check and the
+JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *argv, env=None, timeout=600):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(CTF_BENCH_DRYRUN="1", **(env or {}))
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, env=e, timeout=timeout, cwd=ROOT)
+
+
+def _one_json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_without_torchrun_starts_two_ranks():
+    r = _run("bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["ranks_ok"] is True
+    assert line["per_rank_ms_per_step"] == [1.0, 2.0] and line["ms_per_step"] == 2.0  # the MAX over ranks
+    assert line["config"]["global_envs"] == 2 * line["config"]["envs_per_gpu"]
+    assert line["value"] == pytest.approx(2 * 65536 / 2e-3)
+    assert "DRY RUN" in line["data"]  # a dry-run line can never pass for a measurement
+
+
+def test_gpus_1_is_one_rank_in_process():
+    r = _run("bench.py", "--gpus", "1", "--steps", "3", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == [0]
+    assert "starting" not in r.stderr  # no launcher
+
+
+def test_world_size_that_contradicts_gpus_is_refused():
+    r = _run("bench.py", "--gpus", "2", env=dict(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""
+    r = _run("bench.py", "--gpus", "8", env=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and r.stdout.strip() == ""  # the driver's N=1 form with a wrong --gpus: no mislabelled line
+
+
+def test_more_gpus_than_the_box_has_is_refused():
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CTF_BENCH_DRYRUN")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=e, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "visible" in r.stderr and r.stdout.strip() == ""
+
+
+def test_a_failing_rank_fails_the_job():
+    r = _run("bench.py", "--gpus", "2", "--steps", "2", env=dict(CTF_BENCH_DRYRUN_FAIL_RANK="1"))
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""  # rank 0 never got past the first collective: no line
+
+
+def test_the_launcher_never_imports_torch():
+    """The parent that starts the ranks must not have touched HIP: its code path imports nothing but the standard library."""
+    code = ("import sys, os; sys.argv=['bench.py','--gpus','2','--steps','1']; os.environ['CTF_BENCH_DRYRUN']='1';\n"
+            "import subprocess; subprocess.call=lambda cmd, env=None: (print('CMD', ' '.join(cmd)), 0)[1]\n"
+            "import runpy\n"
+            "try:\n    runpy.run_path('bench.py', run_name='__main__')\nexcept SystemExit as e:\n    print('RC', e.code)\n"
+            "print('TORCH', 'torch' in sys.modules, 'PKG', any('marl' in m for m in sys.modules))")
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, cwd=ROOT, timeout=120)
+    assert "RC 0" in r.stdout and "TORCH False PKG False" in r.stdout, r.stdout + r.stderr
+    cmd = [ln for ln in r.stdout.splitlines() if ln.startswith("CMD")][0]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=2" in cmd and "--master-addr 127.0.0.1" in cmd and cmd.endswith("--gpus 2 --steps 1")

@@ -1,0 +1,73 @@
+"""Shard invariance of the HIP path on ONE GPU: what "rank r of 2" computes for its envs is exactly what one process computes for
+the same global env indices inside a single batch.  This is the property the N-GPU layout rests on (rank r owns global
+envs [lo_r, hi_r), seeds and action streams are functions of the GLOBAL index, no data-path collective) — the reference's
+counterpart is one Ray task per env, each with its own process-global RNG (ppo.py:264-266,349-376)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from _cases import pkg, view_arrays
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+sh = importlib.import_module("marl-ctf-development_amd.sharding")
+
+
+@pytest.mark.parametrize("workload,n_global,rng_mode", [("arena", 2 * 6000 + 1, "mt19937"), ("split", 2 * 3000, "mt19937"),
+                                                         ("arena", 2 * 2048 + 1, "counter")])
+def test_two_shards_equal_the_two_halves_of_one_batch(workload, n_global, rng_mode):
+    if workload == "arena":
+        kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii, GAME_STEPS=40)  # an episode end inside the run
+    else:
+        kw = dict(pkg.configs.SPLIT_KWARGS, SCENARIO=pkg.CtfScenarios.arrow, GAME_STEPS=40)
+    run, steps = 3, 64
+    make = lambda lo, hi: pkg.VecGridworldCtf(hi - lo, device=0, py_seeds=sh.env_seeds(run, lo, hi), np_seeds=sh.env_seeds(run, lo, hi),
+                                              log_metrics=True, tune_placement=False, rng_mode=rng_mode, **kw)
+    whole = make(0, n_global)
+    ranges = [sh.shard_range(n_global, r, 2) for r in range(2)]
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n_global
+    shards = [make(lo, hi) for lo, hi in ranges]
+    N = whole.N_AGENTS
+    a_whole = torch.empty((n_global, N), dtype=torch.int8, device=whole.device)
+    a_shard = [torch.empty((hi - lo, N), dtype=torch.int8, device=whole.device) for lo, hi in ranges]
+    for t in range(steps):
+        whole.random_actions(a_whole, seed=0xC7F, step=t, env_offset=0)
+        rw, dn, ob, mt = whole.step_observe(a_whole, auto_reset=True, want_f64=True)
+        for (lo, hi), vec, acts in zip(ranges, shards, a_shard):
+            vec.random_actions(acts, seed=0xC7F, step=t, env_offset=lo)  # the action stream is a function of the GLOBAL env index
+            assert torch.equal(acts, a_whole[lo:hi]), (t, lo)
+            r2, d2, o2, m2 = vec.step_observe(acts, auto_reset=True, want_f64=True)
+            ctx = f"{workload} step {t} shard [{lo},{hi})"
+            assert torch.equal(vec.rewards64.view(torch.int64), whole.rewards64[lo:hi].view(torch.int64)), ctx + ": f64 rewards"
+            assert torch.equal(r2.view(torch.int32), rw[lo:hi].view(torch.int32)), ctx + ": f32 rewards"
+            assert torch.equal(d2, dn[lo:hi]), ctx + ": done"
+            assert torch.equal(o2, ob[lo:hi]), ctx + ": observations"
+            assert torch.equal(m2.view(torch.int16), mt[lo:hi].view(torch.int16)), ctx + ": metadata"
+            if t % 16 == 15:
+                c2, _ = vec.observe_codes(meta=False)
+                c1, _ = whole.observe_codes(meta=False)
+                assert torch.equal(c2, c1[lo:hi]) and torch.equal(vec.self_cells, whole.self_cells[lo:hi]), ctx + ": compact observation"
+    assert int(whole.counters()[2].max()) < 40  # the episodes did end and were reset inside the launch
+    m1, c1, s1 = whole.counters()
+    if rng_mode == "mt19937":
+        py1, np1 = whole.get_rng_states()
+    else:
+        ctr1 = whole.get_rng_counters()
+    for (lo, hi), vec in zip(ranges, shards):
+        m2, c2, s2 = vec.counters()
+        assert torch.equal(m2, m1[lo:hi]) and torch.equal(c2, c1[lo:hi]) and torch.equal(s2, s1[lo:hi]), "counters"
+        if rng_mode == "mt19937":
+            py2, np2 = vec.get_rng_states()
+            assert torch.equal(py2, py1[lo:hi]) and torch.equal(np2, np1[lo:hi]), "both generators' states"
+        else:
+            assert torch.equal(vec.get_rng_counters(), ctr1[lo:hi]), "words consumed"
+        for e in (lo, (lo + hi) // 2, hi - 1):  # full state views incl. the visitation maps, first / middle / last env of the shard
+            a = view_arrays(whole.get_state(e), N, whole.GRID_SIZE)
+            b = view_arrays(vec.get_state(e - lo), N, whole.GRID_SIZE)
+            for k in a:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (e, k)
+        assert vec.status() == 0
+        vec.close()
+    assert whole.status() == 0
+    whole.close()
