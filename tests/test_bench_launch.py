@@ -76,3 +76,15 @@ def test_the_launcher_never_imports_torch():
     assert "RC 0" in r.stdout and "TORCH False PKG False" in r.stdout, r.stdout + r.stderr
     cmd = [ln for ln in r.stdout.splitlines() if ln.startswith("CMD")][0]
     assert "torch.distributed.run" in cmd and "--nproc-per-node=2" in cmd and "--master-addr 127.0.0.1" in cmd and cmd.endswith("--gpus 2 --steps 1")
+
+
+def test_bench_rollout_gpus_2_runs_the_two_rank_iteration():
+    """configs[4] for N ranks: the launcher, a parameter broadcast, and the data-parallel update over gloo — every rank ends with
+    the same parameters."""
+    r = _run("bench_rollout.py", "--gpus", "2", "--steps", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["parameters_identical_on_all_ranks"] is True
+    assert "DRY RUN" in line["metric"]
+    r = _run("bench_rollout.py", "--gpus", "2", env=dict(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and r.stdout.strip() == ""

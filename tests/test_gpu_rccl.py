@@ -96,3 +96,51 @@ def test_collector_hands_the_full_compact_rollout_over_rccl():
         vec.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_data_parallel_ppo_update_over_rccl_with_one_rank():
+    """learner.PPOLearner's N-rank path (global permutation from a broadcast seed, advantage statistics and the flat gradient through
+    all-reduces) over real RCCL in a one-rank group, on the native policy: with one rank the global minibatches ARE the local ones, so
+    the result must equal the plain single-process update with the same order source — parameters to float32 round-off (the
+    normalisation's statistics come from float64 sums on that path), and both move away from the initial weights."""
+    import copy
+    import os, sys
+
+    import numpy as np
+    import torch.distributed as dist
+
+    learner = importlib.import_module("marl-ctf-development_amd.learner")
+    pn = importlib.import_module("marl-ctf-development_amd.policy_native")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _policy_weights import fill_
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        c, g, m, S, E = 14, 15, 22, 8, 96
+        gen = torch.Generator().manual_seed(5)
+        r = lambda *shape: torch.rand(*shape, generator=gen)
+        codes = torch.randint(0, c, (S, E, g, g), generator=gen).to(torch.uint8)
+        rollout = dict(grid_codes=codes, metadata_states=r(S, E, m).half().float(), actions=torch.randint(0, 9, (S, E), generator=gen).float(),
+                       use_action_mask=torch.randint(0, 2, (S, E), generator=gen).float(), logprobs=-2.2 + 0.3 * r(S, E), rewards=r(S, E) - 0.4,
+                       dones=torch.zeros(S, E), values=0.3 * r(S, E), next_grid_codes=codes[0].clone(), next_metadata_state=r(E, m).half().float(),
+                       next_done=torch.zeros(E))
+        rollout = {k: v.to(dev) for k, v in rollout.items()}
+        args = dict(update_epochs=2, num_minibatches=4)
+        base = fill_(pn.CtfPolicyNative(9, c, g, m)).to(dev)
+        first = torch.cat([p.detach().reshape(-1) for p in base.parameters()]).clone()
+        nets = [copy.deepcopy(base), copy.deepcopy(base)]
+        np.random.seed(11)
+        l_dp = learner.PPOLearner(nets[0], c, world=1, rank=0, force_collective=True, **args).update(rollout, micro_batch=100)
+        np.random.seed(11)
+        l_sp = learner.PPOLearner(nets[1], c, order="device", **args).update(rollout, micro_batch=100)
+        a, b = (torch.cat([p.detach().reshape(-1) for p in n.parameters()]) for n in nets)
+        assert float((a - first).abs().max()) > 1e-4
+        assert float((a - b).abs().max()) < 2e-5, float((a - b).abs().max())  # bf16 kernels + atomics in the weight gradients: not bit-stable
+        assert np.allclose(l_dp, l_sp, rtol=2e-3, atol=2e-4), (l_dp, l_sp)
+    finally:
+        dist.destroy_process_group()
