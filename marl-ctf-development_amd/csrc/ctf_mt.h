@@ -30,7 +30,7 @@
 
 #include "../../include/ctf_env.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define CTF_HD __host__ __device__ __forceinline__
 #else
 #define CTF_HD static inline
