@@ -91,6 +91,12 @@ def visible_gpus():
         return 0
 
 
+def single_rank_rendezvous():
+    """CTF_FORCE_DIST=1 without a launcher: the env:// rendezvous of a one-rank group (rehearsal of the N > 1 code path on one GPU)."""
+    if "RANK" not in os.environ:
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+
+
 def world_or_launch(gpus, script, argv):
     """The launch rule of `--gpus N`, shared by bench.py and bench_rollout.py.
 
@@ -366,6 +372,7 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
+        single_rank_rendezvous()
         if dryrun:
             dist.init_process_group("gloo")
         else:
@@ -466,7 +473,7 @@ def main():
             try:  # BASELINE configs[4] on one GPU: self-play rollout (env + two policy networks) + the reference's PPO update
                 import bench_rollout
 
-                sec["ppo_selfplay_65536x16"] = bench_rollout.run(envs=65536, steps=16, device=local_rank)
+                sec["ppo_selfplay_65536x16"] = bench_rollout.run(envs=65536, steps=16, device=local_rank, order="device")
             except Exception as exc:  # a secondary must never cost the headline line
                 sec["ppo_selfplay_65536x16"] = {"error": repr(exc)}
             line["secondary"] = sec

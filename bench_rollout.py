@@ -35,7 +35,7 @@ def _sync(torch, dist, device):
 
 
 def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update_epochs=4, num_minibatches=4, device=0, micro_batch=1 << 20,
-        rank=0, world=1, dist=None, run_seed=1, order=None):
+        rank=0, world=1, dist=None, run_seed=1, order=None, force_dp=False):
     """-> dict: rollout / update / total env-steps per second of one PPO iteration (rollout of `steps` env steps of `envs`
     envs PER RANK, then `update_epochs` x `num_minibatches` minibatch updates over the world * envs * steps * 4 samples)."""
     import torch
@@ -109,7 +109,7 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         del throwaway, adv, ret
         log("warm-up done; timed update ...")
         lrn = learner.PPOLearner(nets[0], vec.N_CHANNELS, world=world, rank=rank, order=order, update_epochs=update_epochs,
-                                 num_minibatches=num_minibatches)
+                                 num_minibatches=num_minibatches, force_collective=force_dp)
         _sync(torch, dist, dev)
         t2 = time.perf_counter()
         losses = lrn.update(out, micro_batch=micro)  # (no progress callback: it would read the losses back after every minibatch)
@@ -125,7 +125,7 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
             "note": "the learner is the reference's PPO update (ppo.py:174-242) on the compact rollout: the native conv front as the forward "
                     "(ctf_policy_features_train), native data- and weight-gradient kernels (ctf_policy_front_dgrad / _wgrad), hipBLASLt GEMMs "
                     "for the dense layers (policy_native._NativeFront)" +
-                    ("; data-parallel over the global minibatches, one flat gradient all-reduce per optimiser step" if world > 1 else ""),
+                    ("; data-parallel over the global minibatches, one flat gradient all-reduce per optimiser step" if lrn.dp else ""),
         })
     else:
         res["value"] = res["rollout_env_steps_per_s"]
@@ -198,6 +198,7 @@ def main():
     if world > 1 or os.environ.get("CTF_FORCE_DIST"):
         import torch.distributed as dist
 
+        bench.single_rank_rendezvous()
         if is_dry:
             dist.init_process_group("gloo")
         else:
@@ -211,7 +212,8 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench_rollout.py needs a GPU: there is no CPU fallback")
         res = run(args.envs, args.steps, args.policy, args.dtype, not args.no_update, args.update_epochs, args.num_minibatches,
-                  device=local_rank, micro_batch=args.micro_batch, rank=rank, world=world, dist=dist, order=args.order)
+                  device=local_rank, micro_batch=args.micro_batch, rank=rank, world=world, dist=dist, order=args.order,
+                  force_dp=dist is not None and world == 1)  # CTF_FORCE_DIST: the N-rank update's collectives over RCCL with one rank
     if rank == 0:
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:

@@ -100,9 +100,12 @@ def test_collector_hands_the_full_compact_rollout_over_rccl():
 
 def test_data_parallel_ppo_update_over_rccl_with_one_rank():
     """learner.PPOLearner's N-rank path (global permutation from a broadcast seed, advantage statistics and the flat gradient through
-    all-reduces) over real RCCL in a one-rank group, on the native policy: with one rank the global minibatches ARE the local ones, so
-    the result must equal the plain single-process update with the same order source — parameters to float32 round-off (the
-    normalisation's statistics come from float64 sums on that path), and both move away from the initial weights."""
+    all-reduces) over real RCCL in a one-rank group.  With one rank the global minibatches ARE the local ones, so the result must equal
+    the plain single-process update with the same order source:
+    * on the float32 stock network (deterministic kernels) to float32 round-off — the normalisation's statistics come from float64
+      sums on the N-rank path, nothing else differs;
+    * on the native network (bf16 MFMA kernels, float atomics in the weight gradients: not run-to-run stable, and Adam turns a
+      gradient near zero into a full step of either sign) no further than two single-process runs are from each other."""
     import copy
     import os, sys
 
@@ -111,6 +114,7 @@ def test_data_parallel_ppo_update_over_rccl_with_one_rank():
 
     learner = importlib.import_module("marl-ctf-development_amd.learner")
     pn = importlib.import_module("marl-ctf-development_amd.policy_native")
+    pol = importlib.import_module("marl-ctf-development_amd.policy")
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from _policy_weights import fill_
 
@@ -131,16 +135,29 @@ def test_data_parallel_ppo_update_over_rccl_with_one_rank():
                        next_done=torch.zeros(E))
         rollout = {k: v.to(dev) for k, v in rollout.items()}
         args = dict(update_epochs=2, num_minibatches=4)
+        params = lambda n: torch.cat([p.detach().reshape(-1) for p in n.parameters()])
+
+        def updated(base, **kw):
+            net = copy.deepcopy(base)
+            np.random.seed(11)
+            losses = learner.PPOLearner(net, c, **kw, **args).update(rollout, micro_batch=100)
+            return params(net), losses
+
+        base = fill_(pol.CtfPolicy(9, c, g, m, compute_dtype=torch.float32)).to(dev)
+        a, l_dp = updated(base, world=1, rank=0, force_collective=True)
+        b, l_sp = updated(base, order="device")
+        assert float((a - params(base)).abs().max()) > 1e-4
+        assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
+        assert np.allclose(l_dp, l_sp, rtol=1e-5, atol=1e-6), (l_dp, l_sp)
+
         base = fill_(pn.CtfPolicyNative(9, c, g, m)).to(dev)
-        first = torch.cat([p.detach().reshape(-1) for p in base.parameters()]).clone()
-        nets = [copy.deepcopy(base), copy.deepcopy(base)]
-        np.random.seed(11)
-        l_dp = learner.PPOLearner(nets[0], c, world=1, rank=0, force_collective=True, **args).update(rollout, micro_batch=100)
-        np.random.seed(11)
-        l_sp = learner.PPOLearner(nets[1], c, order="device", **args).update(rollout, micro_batch=100)
-        a, b = (torch.cat([p.detach().reshape(-1) for p in n.parameters()]) for n in nets)
-        assert float((a - first).abs().max()) > 1e-4
-        assert float((a - b).abs().max()) < 2e-5, float((a - b).abs().max())  # bf16 kernels + atomics in the weight gradients: not bit-stable
-        assert np.allclose(l_dp, l_sp, rtol=2e-3, atol=2e-4), (l_dp, l_sp)
+        a, l_dp = updated(base, world=1, rank=0, force_collective=True)
+        b, l_sp = updated(base, order="device")
+        b2, _ = updated(base, order="device")
+        spread = float((b - b2).abs().max())
+        steps = args["update_epochs"] * args["num_minibatches"] * 2.5e-4  # no parameter can move further than this
+        assert float((a - b).abs().max()) <= max(2 * spread, 0.25 * steps), (float((a - b).abs().max()), spread)
+        assert float((a - b).abs().mean()) < 2e-5
+        assert np.allclose(l_dp, l_sp, rtol=5e-3, atol=5e-4), (l_dp, l_sp)
     finally:
         dist.destroy_process_group()
