@@ -112,6 +112,54 @@ int ctf_policy_head(const uint16_t* fc1_out_dev, int64_t n_samples, const void* 
                     float* logprob_dev, float* entropy_dev, float* value_dev, float* logits_dev, int32_t device_id,
                     void* stream);
 
+/* ---- fc1 without the per-agent activation matrix (round 4; csrc/ctf_policy_fact.hip) -----------------------------------------------
+ * For agents that share a view (same team and reverse flag: their code rows differ only in bit 7), fc1 — linear in tanh(conv2) — splits
+ * into a part per (env, view) and a correction per agent (agent_network.py:15,30-37 computes the same sum per agent in one product):
+ *     fc1(h2_a ++ meta_a) = W_flat . h2_view + W[:, patch(a)] . (h2_a - h2_view)[patch(a)] + W_meta . meta_a + b
+ * with patch(a) = the 5 x 5 conv2 positions x 32 channels an own-position bit reaches.  Four calls per step and view group:
+ *   1. ctf_policy_fact_bucket     agents -> slots, bucketed by own cell (a tile of 128 slots shares one 800-column slice of W)
+ *   2. ctf_policy_features_fact   conv front: ONE row of the view matrix per env + one patch row per agent, written into its slot
+ *   3. (the caller's BLAS)        yview[E][256] = view[E][KV] x W_flat^T   (fp32 out, no bias)
+ *   4. ctf_policy_fc1_patch       y1[agent] = bf16(W_patch(cell) . patch row + yview[env] + b): the input of ctf_policy_head
+ * Activation traffic per 65 536-env arena step: 2 x (1.07 GB view + 0.46 GB patch rows) written and read once, against 2 x 2.2 GB.
+ * grid_size 11 or 15, n_sel <= 4, meta_len <= 32.  Every pointer but agent_sel is a device pointer; calls only enqueue on `stream`. */
+
+/* Row lengths (bf16 elements): the view matrix (32 * PP, PP = (G-4)^2 rounded up to 32; column of channel c, position p as in
+ * ctf_policy_features: ((c / 4) * PP + p) * 4 + c % 4) and the patch rows (25 * 32 deltas, k = 32 * (5 dy + dx) + c; then meta_len
+ * metadata values; zero padding to a multiple of 64).  ctf_policy_fact_max_tiles: tiles of 128 slots a launch can need at most. */
+int32_t ctf_policy_fact_view_stride(int32_t grid_size);
+int32_t ctf_policy_fact_row_stride(int32_t meta_len);
+int32_t ctf_policy_fact_max_tiles(int32_t n_envs, int32_t n_sel, int32_t grid_size);
+
+/*   selfcell_dev     uint16 [n_envs][n_agents] from ctf_observe_codes
+ *   work_dev         int32 [576 + max_tiles]: scratch of the bucketing that ctf_policy_fc1_patch reads (tile count, tile -> own cell);
+ *                    ZERO it once before the first call (every call leaves its histogram part zeroed for the next)
+ *   slot_of_dev      int32 [n_sel * n_envs] out: row k * n_envs + e -> slot
+ *   row_of_slot_dev  int32 [max_tiles * 128] out: slot -> row, -1 in the padding of a bucket's last tile */
+int ctf_policy_fact_bucket(const uint16_t* selfcell_dev, int32_t n_envs, int32_t n_agents, int32_t grid_size, const int32_t* agent_sel,
+                           int32_t n_sel, int32_t* work_dev, int32_t* slot_of_dev, int32_t* row_of_slot_dev, int32_t device_id,
+                           void* stream);
+
+/* codes / meta / fragments / biases as for ctf_policy_features (same arithmetic, bit for bit, up to tanh(conv2) in bf16).
+ *   view_dev   bf16 [n_envs][ctf_policy_fact_view_stride()]: tanh(conv2) of the view WITHOUT any own-position bit
+ *   prow_dev   bf16 [max_tiles * 128][ctf_policy_fact_row_stride()]: row slot_of[k][e] = bf16(bf16(h2 of agent k) - bf16(h2 of the
+ *              view)) on the agent's 25 patch positions (0 where a position lies outside the image), then its metadata as bf16 */
+int ctf_policy_features_fact(const uint8_t* codes_dev, const uint16_t* meta_dev, const uint16_t* selfcell_dev, int32_t n_envs,
+                             int32_t n_agents, int32_t grid_size, int32_t meta_len, const int32_t* agent_sel, int32_t n_sel,
+                             const void* conv1_frag_dev, const float* conv1_bias_dev, const void* conv2_frag_dev,
+                             const float* conv2_bias_dev, const int32_t* slot_of_dev, uint16_t* view_dev, uint16_t* prow_dev,
+                             int32_t device_id, void* stream);
+
+/*   yview_dev        float [n_envs][256]: view x W_flat^T with W_flat = fc1.weight's conv columns * 2 log2(e) in the view's column order
+ *   patch_frag_dev   bf16 [(G-4)^2 + 2][2][8][64][8]: MFMA 32x32x16 A-operand fragments of fc1.weight * 2 log2(e):
+ *                    [p][s][t][lane][j] = W[out = 32 t + (lane & 31)][column of channel 16 s + 8 (lane >> 5) + j at position p];
+ *                    block p = (G-4)^2: zeros; block (G-4)^2 + 1: the metadata columns (k = 16 s + 8 (lane >> 5) + j < meta_len)
+ *   fc1_bias_dev     float [256]: fc1.bias * 2 log2(e)
+ *   y1_dev           bf16 [n_sel * n_envs][256] out: fc1's pre-activation * 2 log2(e), row k * n_envs + e — ctf_policy_head's input */
+int ctf_policy_fc1_patch(const uint16_t* prow_dev, const int32_t* row_of_slot_dev, const int32_t* work_dev, const float* yview_dev,
+                         const void* patch_frag_dev, const float* fc1_bias_dev, int32_t n_envs, int32_t n_sel, int32_t grid_size,
+                         int32_t meta_len, uint16_t* y1_dev, int32_t device_id, void* stream);
+
 const char* ctf_policy_last_error(void);
 
 #ifdef __cplusplus

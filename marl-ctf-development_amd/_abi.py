@@ -146,6 +146,13 @@ SYMBOLS = {
     "ctf_policy_front_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
     "ctf_policy_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P,
                                   C.c_int32, _P]),
+    "ctf_policy_fact_view_stride": (C.c_int32, [C.c_int32]),
+    "ctf_policy_fact_row_stride": (C.c_int32, [C.c_int32]),
+    "ctf_policy_fact_max_tiles": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "ctf_policy_fact_bucket": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, C.c_int32, _P]),
+    "ctf_policy_features_fact": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
+                                           _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "ctf_policy_fc1_patch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "ctf_policy_last_error": (C.c_char_p, []),
 }
 

@@ -20,6 +20,7 @@ Numerics: bf16 operands, float32 accumulation; against the float32 reference net
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -81,6 +82,26 @@ def act_column_order(grid_size, meta_len):
     return src
 
 
+def fc1_patch_fragments(fc1_w, grid_size, meta_len):
+    """fc1.weight [256, 32 * P2 + M] (reference column order: channel c of conv2 position p at c * P2 + p, then the metadata) -> the
+    A-operand fragments of ctf_policy_fc1_patch (include/ctf_policy.h): float32 [P2 + 2][2][8][64][8], scaled by 2 log2(e);
+    block P2 is zero (a patch position outside the image), block P2 + 1 holds the metadata columns."""
+    w = np.asarray(fc1_w, np.float64) * _TWO_LOG2E
+    p2 = (grid_size - 4) ** 2
+    if w.shape != (256, 32 * p2 + meta_len) or meta_len > 32:
+        raise ValueError("the factored fc1 path is built for fc1 = Linear(32 * (G - 4)^2 + M, 256) with M <= 32")
+    lane, j = np.arange(64), np.arange(8)
+    out = np.zeros((p2 + 2, 2, 8, 64, 8), np.float32)
+    n = (32 * np.arange(8)[:, None, None] + (lane & 31)[None, :, None])            # [t, lane, 1]
+    for s in range(2):
+        c = (16 * s + 8 * (lane >> 5)[:, None] + j[None, :])[None, :, :]              # [1, lane, j]: channel / metadata index
+        for p in range(p2):
+            out[p, s] = w[n, c * p2 + p]
+        mcol = np.where(c < meta_len, 32 * p2 + np.minimum(c, meta_len - 1), 0)
+        out[p2 + 1, s] = np.where(c < meta_len, w[n, mcol], 0.0)
+    return out
+
+
 def tail_fragments(fc2_w, fc2_b, action_w, action_b, value_w, value_b):
     """fc2 / head parameters -> the fused tail kernel's operands (include/ctf_policy.h, ctf_policy_head): bf16 MFMA
     A-fragments (fc2 scaled by 2 log2(e): its output only feeds a tanh) and float32 biases."""
@@ -126,6 +147,14 @@ def gather_maps(n_channels, n_actions):
     f2t = conv2_transposed_fragments(stand_ins([(32, 16, 3, 3)])[0])
     return dict(f1=idx(f1, _TWO_LOG2E), b1=idx(b1, _TWO_LOG2E), f2=idx(f2, _TWO_LOG2E), b2=idx(b2, _TWO_LOG2E),
                 t2=idx(t2, _TWO_LOG2E), tb2=idx(tb2, _TWO_LOG2E), th=idx(th, 1.0), tbh=idx(tbh, 1.0), f2t=idx(f2t, 1.0))
+
+
+def fc1_patch_map(grid_size, meta_len):
+    """fc1_patch_fragments as a gather of fc1.weight.reshape(-1) (-1: a zero), derived like gather_maps: an integer stand-in pushed
+    through the host-side definition."""
+    n = 256 * (32 * (grid_size - 4) ** 2 + meta_len)
+    stand_in = np.arange(1, n + 1, dtype=np.float64).reshape(256, -1)
+    return np.rint(np.asarray(fc1_patch_fragments(stand_in, grid_size, meta_len), np.float64) / _TWO_LOG2E).astype(np.int64) - 1
 
 
 class _NativeFront(torch.autograd.Function):
@@ -180,6 +209,8 @@ class _NativeFront(torch.autograd.Function):
 class CtfPolicyNative(CtfPolicy):
     native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
+    factored_fc1 = os.environ.get("CTF_POLICY_FACT", "1") != "0"  # act_from_codes(shared_view=True): fc1 as one GEMM row per (env, view) + a per-agent patch product
+                            # (ctf_policy_features_fact / ctf_policy_fc1_patch) instead of one activation row per agent
 
     def __init__(self, n_actions, n_channels, grid_size, metadata_size, seed=None):
         super().__init__(n_actions, n_channels, grid_size, metadata_size, compute_dtype=torch.bfloat16)
@@ -254,6 +285,8 @@ class CtfPolicyNative(CtfPolicy):
             maps = {k: torch.from_numpy(v).to(dev) for k, v in gather_maps(self.n_channels, self.n_actions).items()}
             maps.update(dev=dev, kp=len(order), col_src=torch.from_numpy(np.maximum(order, 0)).to(dev),
                         col_keep=torch.from_numpy((order >= 0).astype(np.float32)).to(dev))
+            if self.fact_supported():
+                maps["pf"] = torch.from_numpy(fc1_patch_map(self.grid_size, self.metadata_size)).to(dev)
             assert lib.ctf_policy_act_stride(self.grid_size, self.metadata_size) == len(order)
             self._maps = maps
         m = self._maps
@@ -279,6 +312,11 @@ class CtfPolicyNative(CtfPolicy):
                 th=take(tail, m["th"], 1.0, bf), tbh=take(tail, m["tbh"], 1.0, f32),
                 col_src=m["col_src"], col_keep=m["col_keep"], f2t=take(w2, m["f2t"], 1.0, bf),
             )
+            if "pf" in m:  # the factored fc1 path (ctf_policy_fc1_patch): W_flat in the view's column order, the per-position fragments, the bias
+                kv = lib.ctf_policy_fact_view_stride(self.grid_size)
+                self._prep.update(fc1_view_wt=self._prep["fc1_w"][:, :kv].t().contiguous(),  # [KV, 256]: the GEMM's right operand as it is
+                                  pf=take(self.fc1.weight.detach().reshape(-1).double(), m["pf"], _TWO_LOG2E, bf),
+                                  fc1_b32=(self.fc1.bias.detach().double() * _TWO_LOG2E).to(f32).contiguous())
         return self
 
     def _stamp(self):
@@ -324,6 +362,64 @@ class CtfPolicyNative(CtfPolicy):
         if rc != 0:
             raise _abi.CtfLibraryError("ctf_policy_features: " + (p["lib"].ctf_policy_last_error() or b"").decode())
         return out
+
+    # -- fc1 carried through the shared view (include/ctf_policy.h, "fc1 without the per-agent activation matrix") ------------------
+    def fact_supported(self):
+        return self.grid_size in (11, 15) and self.metadata_size <= 32 and self.metadata_size % 2 == 0
+
+    def _fact_buffers(self, E, A, dev):
+        p = self._ready()
+        lib = p["lib"]
+        key = ("fact", E, A, dev.index)
+        b = self._act_bufs.get(key)
+        if b is None:
+            kv, kr = lib.ctf_policy_fact_view_stride(self.grid_size), lib.ctf_policy_fact_row_stride(self.metadata_size)
+            tiles = lib.ctf_policy_fact_max_tiles(E, A, self.grid_size)
+            i32 = dict(dtype=torch.int32, device=dev)
+            b = dict(kv=kv, kr=kr, tiles=tiles,
+                     view=torch.empty((E, kv), dtype=torch.bfloat16, device=dev),
+                     prow=torch.zeros((tiles * 128, kr), dtype=torch.bfloat16, device=dev),  # (zeros: the padding slots of a bucket hold finite values)
+                     yview=torch.empty((E, 256), dtype=torch.float32, device=dev),
+                     y1=torch.empty((A * E, 256), dtype=torch.bfloat16, device=dev),
+                     work=torch.zeros(576 + tiles, **i32), slot_of=torch.zeros(A * E, **i32), row_of_slot=torch.zeros(tiles * 128, **i32))
+            self._act_bufs[key] = b
+        return b
+
+    def fc1_from_codes_factored(self, codes, meta, agent_idx, self_cells):
+        """fc1's scaled pre-activation (bf16 [len(agent_idx) * E, 256], what ctf_policy_head consumes) for agents that SHARE A VIEW, without
+        the per-agent activation matrix: bucket by own cell, conv front -> view rows + patch rows, one GEMM over the E view rows, the
+        per-agent patch product."""
+        p = self._ready()
+        lib = p["lib"]
+        E, N = int(codes.shape[0]), int(codes.shape[1])
+        sel = [int(i) for i in (agent_idx.tolist() if hasattr(agent_idx, "tolist") else agent_idx)]
+        A, dev = len(sel), codes.device
+        if not (codes.is_cuda and codes.dtype == torch.uint8 and codes.is_contiguous() and tuple(codes.shape[2:]) == (self.grid_size,) * 2):
+            raise ValueError("codes must be a contiguous uint8 CUDA tensor [E, N, G, G]")
+        if not (meta.is_cuda and meta.dtype == torch.float16 and meta.is_contiguous() and tuple(meta.shape) == (E, N, self.metadata_size)):
+            raise ValueError("meta must be a contiguous float16 CUDA tensor [E, N, M]")
+        if not (self_cells is not None and self_cells.is_cuda and self_cells.dtype == torch.int16 and self_cells.is_contiguous() and tuple(self_cells.shape) == (E, N)):
+            raise ValueError("self_cells must be a contiguous int16 CUDA tensor [E, N]")
+        if not (1 <= A <= 4 and self.fact_supported()):
+            raise ValueError("the factored fc1 path takes 1..4 agents of one view, grid_size 11 or 15, metadata_size <= 32")
+        b = self._fact_buffers(E, A, dev)
+        sel_arr = (C.c_int32 * A)(*sel)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        G, M = self.grid_size, self.metadata_size
+
+        def ok(rc, what):
+            if rc != 0:
+                raise _abi.CtfLibraryError(what + ": " + (lib.ctf_policy_last_error() or b"").decode())
+
+        ok(lib.ctf_policy_fact_bucket(ptr(self_cells), E, N, G, sel_arr, A, ptr(b["work"]), ptr(b["slot_of"]), ptr(b["row_of_slot"]),
+                                      dev.index, stream), "ctf_policy_fact_bucket")
+        ok(lib.ctf_policy_features_fact(ptr(codes), ptr(meta), ptr(self_cells), E, N, G, M, sel_arr, A, ptr(p["f1"]), ptr(p["b1"]), ptr(p["f2"]),
+                                        ptr(p["b2"]), ptr(b["slot_of"]), ptr(b["view"]), ptr(b["prow"]), dev.index, stream), "ctf_policy_features_fact")
+        torch.mm(b["view"], p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"])  # float32 out: the patch product is added before the one rounding
+        ok(lib.ctf_policy_fc1_patch(ptr(b["prow"]), ptr(b["row_of_slot"]), ptr(b["work"]), ptr(b["yview"]), ptr(p["pf"]), ptr(p["fc1_b32"]),
+                                    E, A, G, M, ptr(b["y1"]), dev.index, stream), "ctf_policy_fc1_patch")
+        return b["y1"]
 
     # -- the forward of a training step ----------------------------------------------------------------
     def features_train(self, codes, meta, want_h0=True):
@@ -441,6 +537,11 @@ class CtfPolicyNative(CtfPolicy):
         """get_action_and_value (agent_network.py:63-81) for agents ``agent_idx`` of every env, from the compact observation:
         -> (action int32 [B], log_prob [B], entropy [B], value [B, 1]).  Sampling: inverse CDF of the masked softmax with one
         Philox4x32-10 uniform per sample, keyed by this module's seed and call count."""
-        feats = self._features_tuned(codes, meta, agent_idx, shared_view, self_cells)
-        act, logprob, entropy, value, _ = self._tail(feats, mask=masking_decision_tensor, given=action)
+        n_sel = len(agent_idx)
+        if shared_view and self.factored_fc1 and self_cells is not None and n_sel <= 4 and self.fact_supported():
+            y1 = self.fc1_from_codes_factored(codes, meta, agent_idx, self_cells)
+            act, logprob, entropy, value, _ = self._head(y1, mask=masking_decision_tensor, given=action)
+        else:
+            feats = self._features_tuned(codes, meta, agent_idx, shared_view, self_cells)
+            act, logprob, entropy, value, _ = self._tail(feats, mask=masking_decision_tensor, given=action)
         return act, logprob, entropy, value.reshape(-1, 1)

@@ -449,6 +449,7 @@ def test_overlapping_the_two_teams_policy_kernels_changes_no_result():
         torch.manual_seed(11)
         a = fill_(native.CtfPolicyNative(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN, seed=101)).cuda()
         b = fill_(native.CtfPolicyNative(9, vec.N_CHANNELS, vec.GRID_SIZE, vec.META_LEN, seed=202)).cuda()
+        a.factored_fc1 = b.factored_fc1 = False  # the overlapped order exists for the activation-matrix path only (rollout._two_teams_overlapped)
         col = rollout.BatchedRolloutCollector(vec, 12, 0)
         col.overlap_teams = overlap
         out = col.collect(a, b)

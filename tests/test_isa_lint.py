@@ -75,7 +75,8 @@ def test_lint_accepts_a_wait_in_the_issuing_iteration_and_sees_register_ranges(t
 
 @pytest.mark.parametrize("target,listing,users", [("asm", "ctf_kernels.s", ("k_observeILi16E", "k_observeILi4E", "k_observeILi1E")),
                                                   ("asm-policy", "ctf_policy.s", ("k_policy_featuresILi11E", "k_policy_featuresILi15E",
-                                                                                  "k_policy_features_teamILi11E", "k_policy_features_teamILi15E"))])
+                                                                                  "k_policy_features_teamILi11E", "k_policy_features_teamILi15E")),
+                                                  ("asm-policy-fact", "ctf_policy_fact.s", ("k_policy_features_factILi11E", "k_policy_features_factILi15E"))])
 def test_shipped_kernels_keep_their_prefetch_registers_untouched(target, listing, users):
     """The idiom's users: the wave-per-env render (k_observe: next env's record / grid dword) and both policy front kernels
     (G = 11 and 15).  k_observe_tiles, k_step and the rest load through the compiler."""
@@ -86,4 +87,4 @@ def test_shipped_kernels_keep_their_prefetch_registers_untouched(target, listing
         assert any(u in k for k in summary), f"{u}: the hand-placed loads were not recognised"
     assert bad == [], "\n".join(f"{k}:{l}: `{t}` touches in-flight v{r}" for k, l, t, r in bad)
     n_kernels = len(isa_lint.parse_functions(os.path.join(CSRC, listing)))
-    assert n_kernels >= 6, "the listing was not parsed into its kernels"
+    assert n_kernels >= (6 if target != "asm-policy-fact" else 5), "the listing was not parsed into its kernels"

@@ -60,6 +60,31 @@ def main():
         out["trunk_from_codes"] = timed(lambda: net.trunk_from_codes(codes, meta, sel))
         mask = torch.ones(B, device="cuda")
         out["act_from_codes"] = timed(lambda: net.act_from_codes(codes, meta, sel, mask))
+        # round 4: fc1 carried through the shared view, stage by stage for the two teams of a step (include/ctf_policy.h)
+        import ctypes as C
+
+        lib = p["lib"]
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        G, M, N, sc = vec.GRID_SIZE, vec.META_LEN, vec.N_AGENTS, vec.self_cells
+        net.fc1_from_codes_factored(codes, meta, teams[0], sc)
+        b = net._act_bufs[("fact", E, len(teams[0]), 0)]
+        arr = [(C.c_int32 * len(t))(*t) for t in teams]
+        A = len(teams[0])
+        out["fact_bucket_x2"] = timed(lambda: [lib.ctf_policy_fact_bucket(ptr(sc), E, N, G, arr[t], A, ptr(b["work"]), ptr(b["slot_of"]),
+                                                                           ptr(b["row_of_slot"]), 0, st()) for t in (0, 1)])
+        out["fact_front_x2"] = timed(lambda: [lib.ctf_policy_features_fact(ptr(codes), ptr(meta), ptr(sc), E, N, G, M, arr[t], A, ptr(p["f1"]), ptr(p["b1"]),
+                                                                            ptr(p["f2"]), ptr(p["b2"]), ptr(b["slot_of"]), ptr(b["view"]), ptr(b["prow"]), 0, st())
+                                              for t in (0, 1)])
+        out["fact_view_gemm_x2"] = timed(lambda: [torch.mm(b["view"], p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"]) for t in (0, 1)])
+        out["fact_patch_x2"] = timed(lambda: [lib.ctf_policy_fc1_patch(ptr(b["prow"]), ptr(b["row_of_slot"]), ptr(b["work"]), ptr(b["yview"]), ptr(p["pf"]),
+                                                                        ptr(p["fc1_b32"]), E, A, G, M, ptr(b["y1"]), 0, st()) for t in (0, 1)])
+        out["fact_fc1_from_codes_x2"] = timed(lambda: [net.fc1_from_codes_factored(codes, meta, teams[t], sc) for t in (0, 1)])
+        masks = [torch.ones(A * E, device="cuda") for _ in (0, 1)]
+        out["act_two_teams_factored"] = timed(lambda: [net.act_from_codes(codes, meta, teams[t], masks[t], shared_view=True, self_cells=sc) for t in (0, 1)])
+        net.factored_fc1 = False
+        out["act_two_teams_unfactored"] = timed(lambda: [net.act_from_codes(codes, meta, teams[t], masks[t], shared_view=True, self_cells=sc) for t in (0, 1)])
+        net.factored_fc1 = True
     out = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}
     out["samples_per_s_act"] = round(B / (out["act_from_codes"] * 1e-3))
     flop = 2 * (169 * 16 * 14 * 9 + 121 * 32 * 16 * 9)
