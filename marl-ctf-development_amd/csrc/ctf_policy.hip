@@ -1057,13 +1057,15 @@ extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t*
 //   dW2[o][i][tap] = sum over samples, conv2 output positions (y, x) of dz2[o][y][x] * h1[i][y + dy][x + dx]
 //   dW1[o][c][tap] = sum over samples, conv1 output positions (y, x) of dz1[o][y][x] * x0[c][y + dy][x + dx]      (x0: the one-hot image)
 // One 16x16x32 MFMA contracts 32 positions = two image rows of 16 columns (the columns past the row's end are zeros of the A operand).
-// Both operands must then be POSITION-contiguous per lane (8 consecutive x of one channel = one ds_read_b128), i.e. transposed against
-// the channels-last tensors the other kernels exchange; the wave transposes them into LDS with 2-byte stores:
-//   A  [m = out channel][row][16 cols]                      the gradient image, tap-independent, row `rows` and cols >= width zero
-//   B  [dx][n = in channel][row][16 cols]                   the activation image, three copies shifted left by dx = 0, 1, 2 so that the
-//                                                           16-byte reads of every tap are aligned; entry [dx][n][r][c] = img[n][r][c + dx]
+// Both operands must then be POSITION-contiguous per lane (8 consecutive x of one channel), i.e. transposed against the channels-last
+// tensors the other kernels exchange.  Round 3 transposed them into LDS with 2-byte stores (112 store instructions per sample and
+// wave: 1.5 ms per launch for 0.2 ms of MFMAs).  Round 4: the images stay CHANNELS-LAST in LDS — whole 16-byte pieces as they arrive,
+// 14 stores — and gfx950's transposing read delivers the operands: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i
+// (= channel) of a block of 4 rows (= 4 consecutive positions), so an operand register pair is two such reads:
+//   A  [RA rows][16 cols][CO channels]     the gradient image; rows >= GO and cols >= GO stay zero
+//   B  [RB rows][18 cols][16 channels]     the activation image; a tap (dy, dx) reads it from row + dy, column + dx on
 // Accumulators (one f32x4 tile per tap and 16 out channels) live in registers across all samples of the wave; at the end the block's
-// four waves are summed through LDS and added to the float32 result with one atomicAdd per element and block.
+// waves are summed through LDS and added to the float32 result with one atomicAdd per element and block.
 struct WgradArgs {
     const uint16_t* grad;    // bf16 channels-last [S][GO*GO][CO]: dz2 (CO = 32) or dz1 (CO = 16)
     const uint16_t* img;     // bf16 channels-last [S][GI*GI][16]: h1, or NULL when the image is built from codes
@@ -1071,8 +1073,16 @@ struct WgradArgs {
     float* dw;               // float [CO][16][9] += (the caller zeroes it)
     int64_t S;
 };
+typedef short i16x4_t __attribute__((ext_vector_type(4)));
+// two transposed 4-position blocks (4 positions apart) -> one 8-position MFMA operand of this lane's channel
+__device__ __forceinline__ u32x4_t wgrad_tr_operand(const uint8_t* lds_addr, int second_block_bytes) {
+    typedef __attribute__((address_space(3))) i16x4_t* lds_v4;
+    const i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_addr));
+    const i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_addr + second_block_bytes));
+    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+    return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
+}
 // GO: side of the gradient image, GI = GO + 2: side of the activation image, CO: out channels (16 or 32)
-typedef uint32_t u32x4_a2_t __attribute__((ext_vector_type(4), aligned(2)));  // a 16-byte LDS read at a 2-byte aligned address
 template <int GO, int CO, bool FROM_CODES>
 __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
     extern __shared__ uint32_t lds[];
@@ -1080,9 +1090,10 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
     constexpr int RA = GO + 1 + (GO & 1 ? 0 : 1);      // rows of A: GO + at least one zero row, an even count
     constexpr int KS = RA / 2;                          // K-steps (two rows each)
     constexpr int RB = RA + 2;                          // rows of B read: up to RA - 1 + 2
-    constexpr int A_CH = RA * 32 + 16, B_ROW = 48, B_CH = RB * B_ROW + 16;  // bytes: per channel of A (padded against bank conflicts of the
-                                                        // transposing stores), per row of B (24 columns: a tap's read starts at column <= 10)
-    constexpr int A_BYTES = CO * A_CH, B_BYTES = 16 * B_CH;
+    constexpr int WB = 18;                              // columns of B read: up to 15 + 2
+    constexpr int A_POS = CO * 2, A_ROW = 16 * A_POS;  // bytes per position / per row of A
+    constexpr int B_POS = 32, B_ROW = WB * B_POS;
+    constexpr int A_BYTES = RA * A_ROW, B_BYTES = RB * B_ROW;
     constexpr int NH = CO / 16;                         // 16-channel halves of the out channels
     constexpr int NPA = PO * (CO / 8), NA = (NPA + WAVE - 1) / WAVE;             // 16-byte pieces of the gradient image, per lane
     constexpr int NPB = FROM_CODES ? PI : PI * 2, NB = (NPB + WAVE - 1) / WAVE;  // code bytes / 16-byte pieces of the activation image
@@ -1090,7 +1101,7 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), wpb = blockDim.x / WAVE;
     uint8_t* A = (uint8_t*)lds + wave * (A_BYTES + B_BYTES);
     uint8_t* B = A + A_BYTES;
-    {   // zeros everywhere once: the A rows / columns past the image and the B columns past a row's end stay zero
+    {   // zeros everywhere once: the A rows / columns past the image and the B rows / columns past the image stay zero
         const u32x4_t z = {0u, 0u, 0u, 0u};
         for (int q = lane; q < (A_BYTES + B_BYTES) / 16; q += WAVE) ((u32x4_t*)A)[q] = z;
     }
@@ -1100,8 +1111,10 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
 #pragma unroll
         for (int h = 0; h < NH; h++) acc[t][h] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
     const int mn = lane & 15, kg = lane >> 4;           // operand row / column, k-group: row parity kg >> 1, columns 8 (kg & 1) ..
-    const int a_off = mn * A_CH + (kg >> 1) * 32 + (kg & 1) * 16;
-    const int b_off = mn * B_CH + (kg >> 1) * B_ROW + (kg & 1) * 16;
+    // the transposing read: lane 4 q + p of a 16-lane group supplies the address of block row q (position x0 + q), channels 4 p .. 4 p + 3
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int a_off = (kg >> 1) * A_ROW + (8 * (kg & 1) + tq) * A_POS + tp * 8;   // + h * 32 bytes, + ks * 2 * A_ROW
+    const int b_off = (kg >> 1) * B_ROW + (8 * (kg & 1) + tq) * B_POS + tp * 8;   // + (dy * B_ROW + dx * B_POS), + ks * 2 * B_ROW
     // the next sample's inputs travel while this one is contracted: a lane's pieces sit in registers across the MFMA section
     u32x4_t ga[NA], gb[FROM_CODES ? 1 : NB];
     uint32_t cb[FROM_CODES ? NB : 1];
@@ -1122,22 +1135,17 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
     };
     if (s0 < a.S) fetch(s0);
     for (int64_t s = s0; s < a.S; s += stride) {
-        // ---- A: the gradient image, channels-last [PO][CO] -> [CO][RA][16]
+        // ---- A: the gradient image, channels-last [PO][CO] -> [RA][16][CO]: every 16-byte piece as it is, at its (row, column)
 #pragma unroll
         for (int u = 0; u < NA; u++) {
             const int idx = lane + WAVE * u;
             if (idx < NPA) {
                 const int pos = idx / (CO / 8), oct = idx - pos * (CO / 8);
                 const int y = pos / GO, x = pos - y * GO;
-                uint8_t* dst = A + (oct * 8) * A_CH + y * 32 + x * 2;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    *(uint16_t*)(dst + (2 * j) * A_CH) = (uint16_t)(ga[u][j] & 0xFFFFu);
-                    *(uint16_t*)(dst + (2 * j + 1) * A_CH) = (uint16_t)(ga[u][j] >> 16);
-                }
+                *(u32x4_t*)(A + y * A_ROW + x * A_POS + oct * 16) = ga[u];
             }
         }
-        // ---- B: the activation image [16 channels][RB rows][24 columns]
+        // ---- B: the activation image [RB rows][WB columns][16 channels]
         if (FROM_CODES) {
             const u32x4_t z = {0u, 0u, 0u, 0u};
             for (int q = lane; q < B_BYTES / 16; q += WAVE) ((u32x4_t*)B)[q] = z;
@@ -1149,8 +1157,8 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
                 if (c < NPB) {
                     const uint32_t code = cb[u], ch = code & 0x7Fu;
                     const int y = c / GI, x = c - y * GI;
-                    uint8_t* dst = B + y * B_ROW + x * 2;
-                    if (ch != 0 && ch < 16) *(uint16_t*)(dst + ch * B_CH) = 0x3F80;
+                    uint8_t* dst = B + y * B_ROW + x * B_POS;
+                    if (ch != 0 && ch < 16) *(uint16_t*)(dst + ch * 2) = 0x3F80;
                     if (code >> 7) *(uint16_t*)(dst) = 0x3F80;
                 }
             }
@@ -1161,12 +1169,7 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
                 if (idx < NPB) {
                     const int pos = idx >> 1, oct = idx & 1;
                     const int y = pos / GI, x = pos - y * GI;
-                    uint8_t* dst = B + (oct * 8) * B_CH + y * B_ROW + x * 2;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        *(uint16_t*)(dst + (2 * j) * B_CH) = (uint16_t)(gb[u][j] & 0xFFFFu);
-                        *(uint16_t*)(dst + (2 * j + 1) * B_CH) = (uint16_t)(gb[u][j] >> 16);
-                    }
+                    *(u32x4_t*)(B + y * B_ROW + x * B_POS + oct * 16) = gb[u];
                 }
             }
         }
@@ -1176,15 +1179,16 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        // ---- contraction: K-step ks = gradient rows 2 ks, 2 ks + 1; tap (dy, dx) reads the activation rows + dy from column + dx on
+        // ---- contraction: K-step ks = gradient rows 2 ks, 2 ks + 1; tap (dy, dx) reads the activation rows + dy from column + dx on.
+        // (All 64 lanes are active here, as the transposing read requires.)
 #pragma unroll 1
         for (int ks = 0; ks < KS; ks++) {
             u32x4_t av[NH];
 #pragma unroll
-            for (int h = 0; h < NH; h++) av[h] = *(const u32x4_t*)(A + a_off + h * 16 * A_CH + ks * 64);
+            for (int h = 0; h < NH; h++) av[h] = wgrad_tr_operand(A + a_off + h * 32 + ks * 2 * A_ROW, 4 * A_POS);
 #pragma unroll
             for (int t = 0; t < 9; t++) {
-                const u32x4_t bv = *(const u32x4_a2_t*)(B + b_off + (ks * 2 + t / 3) * B_ROW + (t % 3) * 2);
+                const u32x4_t bv = wgrad_tr_operand(B + b_off + (ks * 2 + t / 3) * B_ROW + (t % 3) * B_POS, 4 * B_POS);
 #pragma unroll
                 for (int h = 0; h < NH; h++) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[h]), as_bf16x8(bv), acc[t][h], 0, 0, 0);
             }
@@ -1227,7 +1231,7 @@ extern "C" int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h
     const int wpb = 2;
     auto launch = [&](auto kernel, int go, int co, const WgradArgs& a) {
         const int ra = go + 1 + ((go & 1) ? 0 : 1), rb = ra + 2;
-        size_t sh = (size_t)wpb * ((size_t)co * (ra * 32 + 16) + 16 * ((size_t)rb * 48 + 16));
+        size_t sh = (size_t)wpb * ((size_t)ra * 16 * co * 2 + (size_t)rb * 18 * 32);  // k_policy_front_wgrad's A_BYTES + B_BYTES per wave
         const size_t red = (size_t)wpb * 9 * co * 16 * 4;
         if (sh < red) sh = red;
         int per_cu = (int)((160 * 1024) / sh);
