@@ -923,15 +923,38 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
     float s2[16], s1[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 16; r++) s2[r] = 0.0f;
-    for (int64_t s = (int64_t)blockIdx.x * wpb + wave; s < a.S; s += (int64_t)gridDim.x * wpb) {
-        // h1 of this sample: channels-last [P1][16] -> [2 halves][P1][8]
-        const uint8_t* hsrc = (const uint8_t*)(a.h1 + (size_t)s * P1 * 16);
-        for (int idx = lane; idx < 2 * P1; idx += WAVE) *(u32x4_t*)(h1 + (idx & 1) * H1A + (idx >> 1) * 16) = *(const u32x4_t*)(hsrc + (size_t)idx * 16);
-        const uint16_t* drow = a.d_act + (size_t)s * a.Kp;
-        const uint16_t* arow = a.act + (size_t)s * a.Kp;
-        uint16_t* z2out = a.dz2 + (size_t)s * P2 * 32;
+    // A sample's inputs — its rows of d_act and act (8 bytes per lane, tile and channel quad) and its h1 image (16-byte pieces) — are
+    // requested one sample ahead, right after the registers of the current sample's rows have been consumed: they travel while the
+    // MFMA section runs.  (Round 3 loaded them at the top of their own sample: two exposed HBM round trips per sample and wave.)
+    constexpr int NT2 = PP / 32, NH1 = (2 * P1 + WAVE - 1) / WAVE;
+    u32x2_t gq[NT2][4], hq[NT2][4];
+    u32x4_t h1q[NH1];
+    auto fetch = [&](int64_t sn) {
+        const uint16_t* drow = a.d_act + (size_t)sn * a.Kp;
+        const uint16_t* arow = a.act + (size_t)sn * a.Kp;
 #pragma unroll
-        for (int t = 0; t < PP / 32; t++) {
+        for (int t = 0; t < NT2; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const size_t col = ((size_t)(2 * q + hh) * PP + 32 * t + n2) * 4;  // (positions >= P2 of the last tile: padding columns of the row)
+                gq[t][q] = *(const u32x2_t*)(drow + col);
+                hq[t][q] = *(const u32x2_t*)(arow + col);
+            }
+        const uint8_t* hsrc = (const uint8_t*)(a.h1 + (size_t)sn * P1 * 16);
+#pragma unroll
+        for (int u = 0; u < NH1; u++) h1q[u] = *(const u32x4_t*)(hsrc + (size_t)min(lane + WAVE * u, 2 * P1 - 1) * 16);
+    };
+    const int64_t s_first = (int64_t)blockIdx.x * wpb + wave, s_stride = (int64_t)gridDim.x * wpb;
+    if (s_first < a.S) fetch(s_first);
+    for (int64_t s = s_first; s < a.S; s += s_stride) {
+        // h1 of this sample: channels-last [P1][16] -> [2 halves][P1][8]
+#pragma unroll
+        for (int u = 0; u < NH1; u++) {
+            const int idx = lane + WAVE * u;
+            if (idx < 2 * P1) *(u32x4_t*)(h1 + (idx & 1) * H1A + (idx >> 1) * 16) = h1q[u];
+        }
+#pragma unroll
+        for (int t = 0; t < NT2; t++) {
             const int pa = 32 * t + n2;
             const bool ok = pa < P2;
             const int pc = ok ? pa : P2 - 1;
@@ -939,19 +962,31 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
             uint8_t* cell = zp + ((y + 2) * G + (x + 2)) * 16 + hh * 8;
 #pragma unroll
             for (int q = 0; q < 4; q++) {  // channels 8 q + 4 hh .. + 3: octet q, its half hh
-                const size_t col = ((size_t)(2 * q + hh) * PP + pa) * 4;
-                const u32x2_t g = *(const u32x2_t*)(drow + col), h = *(const u32x2_t*)(arow + col);
                 float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-                const u32x2_t o = {tanh_grad2(g[0], h[0], d0, d1), tanh_grad2(g[1], h[1], d2, d3)};
+                const u32x2_t o = {tanh_grad2(gq[t][q][0], hq[t][q][0], d0, d1), tanh_grad2(gq[t][q][1], hq[t][q][1], d2, d3)};
                 if (ok) {
                     *(u32x2_t*)(cell + q * GG * 16) = o;
-                    *(u32x2_t*)(z2out + (size_t)pa * 32 + 8 * q + 4 * hh) = o;
                     s2[4 * q] += d0; s2[4 * q + 1] += d1; s2[4 * q + 2] += d2; s2[4 * q + 3] += d3;
                 }
             }
         }
+        fetch(s + s_stride < a.S ? s + s_stride : s);  // (behind the last sample it re-reads itself: every lane always issues the same loads)
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        // dz2 out, channels-last [P2][32]: 16-byte pieces (position p, octet q) read back from the padded image — consecutive lanes write
+        // consecutive pieces (straight from the registers above they were 8-byte pieces 64 bytes apart)
+        {
+            uint8_t* z2out = (uint8_t*)(a.dz2 + (size_t)s * P2 * 32);
+#pragma unroll
+            for (int u = 0; u < (4 * P2 + WAVE - 1) / WAVE; u++) {
+                const int idx = lane + WAVE * u;
+                if (idx < 4 * P2) {
+                    const int pos = idx >> 2, q = idx & 3;
+                    const int y = (int)(((uint32_t)pos * a.inv_g2) >> 16), x = pos - y * G2;
+                    *(u32x4_t*)(z2out + (size_t)idx * 16) = *(const u32x4_t*)(zp + q * GG * 16 + ((y + 2) * G + (x + 2)) * 16);
+                }
+            }
+        }
         uint16_t* z1out = a.dz1 + (size_t)s * P1 * 16;
         constexpr int T1 = (P1 + 15) >> 4;
 #pragma unroll 1
