@@ -8,8 +8,8 @@ CS=marl-ctf-development_amd/csrc
 mkdir -p gpurun_out/ablate
 i=0
 for flags in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -shared \
-      -o gpurun_out/ablate/lib$i.so $CS/ctf_abi.hip $CS/ctf_kernels.hip || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off $flags -shared \
+      -o gpurun_out/ablate/lib$i.so $CS/ctf_abi.hip $CS/ctf_kernels.hip $CS/ctf_policy.hip $CS/ctf_policy_fact.hip || exit 1
   i=$((i+1))
 done
 for round in 1 2; do
