@@ -88,6 +88,15 @@ int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t* act_dev, c
 int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h1_dev, const uint16_t* dz1_dev, const uint8_t* codes_dev,
                            int64_t n_samples, int32_t grid_size, float* dw2_dev, float* dw1_dev, int32_t device_id, void* stream);
 
+/* ctf_policy_front_dgrad + both weight gradients as ONE call (round 4): conv2's data and weight gradient in one pass — dz2 stays on the
+ * CU, never written or re-read — then conv1's weight gradient from the dz1 that pass wrote (a scratch of the caller's: bf16
+ * [n_samples][(G-2)^2][16], 16-byte aligned) and the code bytes.  The same sums as the separate calls; dw2 / dw1 / the bias gradients are
+ * added to (the caller zeroes them). */
+int ctf_policy_front_backward(const uint16_t* d_act_dev, const uint16_t* act_dev, const uint16_t* h1_dev, const uint8_t* codes_dev,
+                              const void* conv2_t_frag_dev, int64_t n_samples, int32_t grid_size, int32_t meta_len, uint16_t* dz1_dev,
+                              float* dw2_dev, float* dw1_dev, float* bias2_grad_dev, float* bias1_grad_dev, int32_t device_id,
+                              void* stream);
+
 /* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
  *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)
  *   logits += (mask - 1) * 1e9 with mask = [1]*5 + [0]*(A-5) where the decision is 1, all ones otherwise

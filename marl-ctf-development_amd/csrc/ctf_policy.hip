@@ -873,6 +873,15 @@ extern "C" int ctf_policy_features(const uint8_t* codes_dev, const uint16_t* met
     return 0;
 }
 
+typedef short i16x4_t __attribute__((ext_vector_type(4)));
+// two transposed 4-position blocks (4 positions apart) -> one 8-position MFMA operand of this lane's channel
+__device__ __forceinline__ u32x4_t wgrad_tr_operand(const uint8_t* lds_addr, int second_block_bytes) {
+    typedef __attribute__((address_space(3))) i16x4_t* lds_v4;
+    const i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_addr));
+    const i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_addr + second_block_bytes));
+    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+    return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
+}
 // ---- tanh' * incoming gradient for two bf16 pairs (and their float32 values, for the bias-gradient sums)
 __device__ __forceinline__ uint32_t tanh_grad2(uint32_t g2, uint32_t h2, float& s0, float& s1) {  // two bf16 pairs -> g * (1 - h * h)
     const float g0 = __builtin_bit_cast(float, g2 << 16), g1 = __builtin_bit_cast(float, g2 & 0xFFFF0000u);
@@ -898,15 +907,27 @@ struct DgradArgs {
     uint16_t* dz1;           // bf16 [S][P1][16]
     float* db2;              // float [32] += , or NULL
     float* db1;              // float [16] += , or NULL
+    float* dw2;              // W2 instantiation: float [32][16][9] += conv2's weight gradient (dz2 is then not written at all)
     int64_t S;
     int32_t Kp;
     uint32_t inv_g1, inv_g2;
 };
-template <int TG>
+// W2 = true fuses conv2's WEIGHT gradient into the same pass: dz2 never leaves the CU.  Separate kernels moved, per sample, dz2 out
+// (7.7 KB) and back in (7.7 KB) and h1 in a second time (5.4 KB) — and the weight-gradient kernel, once its transposing stores were
+// gone, ran at the speed of exactly that traffic (0.70 ms per 262 144 samples, 4.9 TB/s).  Both images get the padding the position
+// contraction needs (16 columns per gradient row, 18 per activation row, rows past the image: zeros that nothing ever writes), and
+// the operands come from the images as they lie — dz2 in its four octet arrays, h1 in its two halves — through the transposing read
+// (k_policy_front_wgrad), whose lanes may point anywhere.
+template <int TG, bool W2>
 __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
     extern __shared__ uint32_t lds[];
-    constexpr int G = TG, G1 = G - 2, G2 = G - 4, GG = G * G, P1 = G1 * G1, P2 = G2 * G2, PP = ((P2 + 31) >> 5) << 5;
-    constexpr int ZB = 4 * GG * 16, H1A = (((P1 + 15) >> 4) << 4) * 16;  // bytes: the padded dz2 image (4 octet arrays), one half of h1
+    constexpr int G = TG, G1 = G - 2, G2 = G - 4, P1 = G1 * G1, P2 = G2 * G2, PP = ((P2 + 31) >> 5) << 5;
+    constexpr int RA = G2 + 1 + (G2 & 1 ? 0 : 1), KS = RA / 2;  // the weight gradient's K-steps: two gradient rows of 16 columns each
+    constexpr int ZW = W2 ? 18 : G;                              // cells per row of the padded dz2 image (column x + 2 <= 17 when fused)
+    constexpr int ZCELLS = G * ZW, ZB = 4 * ZCELLS * 16;         // bytes: the padded dz2 image (4 octet arrays)
+    constexpr int H1W = W2 ? 18 : G1, H1R = W2 ? RA + 2 : G1;    // the h1 image: columns / rows (fused: a tap reads up to column 17, row RA + 1)
+    constexpr int H1A = W2 ? H1R * H1W * 16 : (((P1 + 15) >> 4) << 4) * 16;  // bytes of one channel half of it
+    static_assert(!W2 || (RA + 1 < G && H1R > G1), "the zero rows the position contraction reads exist");
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), wpb = blockDim.x / WAVE;
     uint8_t* zp = (uint8_t*)lds + wave * (ZB + 2 * H1A);
@@ -914,10 +935,13 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
     u32x4_t w2t[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) w2t[t] = a.w2t[t * WAVE + lane];
-    {   // the border of the padded image stays zero for the whole launch
+    {   // the border of the padded image (fused: also the h1 image's padding) stays zero for the whole launch
         const u32x4_t z = {0u, 0u, 0u, 0u};
-        for (int q = lane; q < 4 * GG; q += WAVE) ((u32x4_t*)zp)[q] = z;
+        for (int q = lane; q < (W2 ? (ZB + 2 * H1A) / 16 : 4 * ZCELLS); q += WAVE) ((u32x4_t*)zp)[q] = z;
     }
+    f32x4_t acc2[W2 ? 9 : 1][2];
+#pragma unroll
+    for (int t = 0; t < (W2 ? 9 : 1); t++) acc2[t][0] = acc2[t][1] = (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
     const int n2 = lane & 31, hh = lane >> 5;   // dz2 pass: position within a 32-position tile, channel-quad parity
     const int n1 = lane & 15, g1 = lane >> 4;   // data-gradient pass: position within a 16-position tile, octet of o / quad of i
     float s2[16], s1[4] = {0, 0, 0, 0};
@@ -947,11 +971,14 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
     const int64_t s_first = (int64_t)blockIdx.x * wpb + wave, s_stride = (int64_t)gridDim.x * wpb;
     if (s_first < a.S) fetch(s_first);
     for (int64_t s = s_first; s < a.S; s += s_stride) {
-        // h1 of this sample: channels-last [P1][16] -> [2 halves][P1][8]
+        // h1 of this sample: channels-last [P1][16] -> [2 halves][rows][columns][8]
 #pragma unroll
         for (int u = 0; u < NH1; u++) {
             const int idx = lane + WAVE * u;
-            if (idx < 2 * P1) *(u32x4_t*)(h1 + (idx & 1) * H1A + (idx >> 1) * 16) = h1q[u];
+            if (idx < 2 * P1) {
+                const int pos = idx >> 1, y = (int)(((uint32_t)pos * a.inv_g1) >> 16), x = pos - y * G1;
+                *(u32x4_t*)(h1 + (idx & 1) * H1A + (y * H1W + x) * 16) = h1q[u];
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT2; t++) {
@@ -959,13 +986,13 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
             const bool ok = pa < P2;
             const int pc = ok ? pa : P2 - 1;
             const int y = (int)(((uint32_t)pc * a.inv_g2) >> 16), x = pc - y * G2;
-            uint8_t* cell = zp + ((y + 2) * G + (x + 2)) * 16 + hh * 8;
+            uint8_t* cell = zp + ((y + 2) * ZW + (x + 2)) * 16 + hh * 8;
 #pragma unroll
             for (int q = 0; q < 4; q++) {  // channels 8 q + 4 hh .. + 3: octet q, its half hh
                 float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
                 const u32x2_t o = {tanh_grad2(gq[t][q][0], hq[t][q][0], d0, d1), tanh_grad2(gq[t][q][1], hq[t][q][1], d2, d3)};
                 if (ok) {
-                    *(u32x2_t*)(cell + q * GG * 16) = o;
+                    *(u32x2_t*)(cell + q * ZCELLS * 16) = o;
                     s2[4 * q] += d0; s2[4 * q + 1] += d1; s2[4 * q + 2] += d2; s2[4 * q + 3] += d3;
                 }
             }
@@ -975,7 +1002,7 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
         __builtin_amdgcn_wave_barrier();
         // dz2 out, channels-last [P2][32]: 16-byte pieces (position p, octet q) read back from the padded image — consecutive lanes write
         // consecutive pieces (straight from the registers above they were 8-byte pieces 64 bytes apart)
-        {
+        if (!W2) {
             uint8_t* z2out = (uint8_t*)(a.dz2 + (size_t)s * P2 * 32);
 #pragma unroll
             for (int u = 0; u < (4 * P2 + WAVE - 1) / WAVE; u++) {
@@ -983,29 +1010,78 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
                 if (idx < 4 * P2) {
                     const int pos = idx >> 2, q = idx & 3;
                     const int y = (int)(((uint32_t)pos * a.inv_g2) >> 16), x = pos - y * G2;
-                    *(u32x4_t*)(z2out + (size_t)idx * 16) = *(const u32x4_t*)(zp + q * GG * 16 + ((y + 2) * G + (x + 2)) * 16);
+                    *(u32x4_t*)(z2out + (size_t)idx * 16) = *(const u32x4_t*)(zp + q * ZCELLS * 16 + ((y + 2) * ZW + (x + 2)) * 16);
                 }
             }
         }
         uint16_t* z1out = a.dz1 + (size_t)s * P1 * 16;
         constexpr int T1 = (P1 + 15) >> 4;
-#pragma unroll 1
-        for (int t = 0; t < T1; t++) {
-            const int p = 16 * t + n1, pc = p < P1 ? p : P1 - 1;
-            const int yy = (int)(((uint32_t)pc * a.inv_g1) >> 16), xx = pc - yy * G1;
-            const uint8_t* base = zp + g1 * GG * 16 + ((yy + 2) * G + (xx + 2)) * 16;
-            f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int tap = 0; tap < 9; tap++) {
-                const u32x4_t b = *(const u32x4_t*)(base - ((tap / 3) * G + (tap % 3)) * 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w2t[tap]), as_bf16x8(b), acc, 0, 0, 0);
-            }
-            const u32x2_t hv = *(const u32x2_t*)(h1 + (g1 >> 1) * H1A + pc * 16 + (g1 & 1) * 8);  // h1 channels 4 g1 .. + 3 of this position
+        // two tiles per pass: two independent accumulation chains (a chain of nine dependent MFMAs per tile leaves the pipe idle most of
+        // the time when the wave is alone on its SIMD)
+        auto dgrad_tile_base = [&](int t, int& p, int& yy, int& xx) {
+            p = 16 * t + n1;
+            const int pc = p < P1 ? p : P1 - 1;
+            yy = (int)(((uint32_t)pc * a.inv_g1) >> 16);
+            xx = pc - yy * G1;
+            return zp + g1 * ZCELLS * 16 + ((yy + 2) * ZW + (xx + 2)) * 16;
+        };
+        auto dgrad_tile_out = [&](const f32x4_t& acc, int p, int yy, int xx) {
+            const int pc = p < P1 ? p : P1 - 1;
+            const u32x2_t hv = *(const u32x2_t*)(h1 + (g1 >> 1) * H1A + (W2 ? yy * H1W + xx : pc) * 16 + (g1 & 1) * 8);  // h1 channels 4 g1 .. + 3 of this position
             float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
             const u32x2_t o = {tanh_grad2(pack_bf16(acc[0], acc[1]), hv[0], d0, d1), tanh_grad2(pack_bf16(acc[2], acc[3]), hv[1], d2, d3)};
             if (p < P1) {
                 *(u32x2_t*)(z1out + (size_t)p * 16 + 4 * g1) = o;
                 s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+            }
+        };
+        int t = 0;
+#pragma unroll 1
+        for (; t + 1 < T1; t += 2) {
+            int pa_, ya_, xa_, pb_, yb_, xb_;
+            const uint8_t* base_a = dgrad_tile_base(t, pa_, ya_, xa_);
+            const uint8_t* base_b = dgrad_tile_base(t + 1, pb_, yb_, xb_);
+            f32x4_t acc_a = {0.0f, 0.0f, 0.0f, 0.0f}, acc_b = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int off = ((tap / 3) * ZW + (tap % 3)) * 16;
+                const u32x4_t ba = *(const u32x4_t*)(base_a - off);
+                const u32x4_t bb = *(const u32x4_t*)(base_b - off);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w2t[tap]), as_bf16x8(ba), acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w2t[tap]), as_bf16x8(bb), acc_b, 0, 0, 0);
+            }
+            dgrad_tile_out(acc_a, pa_, ya_, xa_);
+            dgrad_tile_out(acc_b, pb_, yb_, xb_);
+        }
+        if (t < T1) {
+            int pa_, ya_, xa_;
+            const uint8_t* base_a = dgrad_tile_base(t, pa_, ya_, xa_);
+            f32x4_t acc_a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const u32x4_t ba = *(const u32x4_t*)(base_a - ((tap / 3) * ZW + (tap % 3)) * 16);
+                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w2t[tap]), as_bf16x8(ba), acc_a, 0, 0, 0);
+            }
+            dgrad_tile_out(acc_a, pa_, ya_, xa_);
+        }
+        if (W2) {
+            // ---- conv2's weight gradient: dW2[o][i][tap] += sum over positions of dz2[o][y][x] * h1[i][y + dy][x + dx].  K-step ks = gradient
+            // rows 2 ks, 2 ks + 1; lane 4 q + p of a 16-lane group supplies block row q (position x0 + q) and channels 4 p .. 4 p + 3:
+            // octet (p >> 1) + 2 h of dz2 / half p >> 1 of h1, 8 bytes in.  (All 64 lanes are active, as the transposing read requires.)
+            const int kg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+            const int za = (tp >> 1) * ZCELLS * 16 + (((kg >> 1) + 2) * ZW + 8 * (kg & 1) + tq + 2) * 16 + (tp & 1) * 8;
+            const int hb = (tp >> 1) * H1A + ((kg >> 1) * H1W + 8 * (kg & 1) + tq) * 16 + (tp & 1) * 8;
+#pragma unroll 1
+            for (int ks = 0; ks < KS; ks++) {
+                u32x4_t av[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) av[h] = wgrad_tr_operand(zp + za + h * 2 * ZCELLS * 16 + ks * 2 * ZW * 16, 4 * 16);
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const u32x4_t bv = wgrad_tr_operand(h1 + hb + ((ks * 2 + t / 3) * H1W + t % 3) * 16, 4 * 16);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) acc2[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[h]), as_bf16x8(bv), acc2[t][h], 0, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1039,6 +1115,23 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
             atomicAdd(a.db1 + c, t);
         }
     }
+    if (W2) {  // the block's four partial weight gradients -> one; D tile: lane holds rows m = 4 (lane >> 4) + r of column n = lane & 15
+        __syncthreads();
+        const int mn = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[((wave * 9 + t) * 32 + 16 * h + 4 * kg + r) * 16 + mn] = acc2[W2 ? t : 0][h][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 9 * 32 * 16; e += blockDim.x) {
+            float v = 0.0f;
+            for (int w = 0; w < wpb; w++) v += red[w * 9 * 32 * 16 + e];
+            const int t = e / (32 * 16), oi = e - t * (32 * 16);
+            atomicAdd(a.dw2 + (size_t)oi * 9 + t, v);  // [out][in][tap]
+        }
+    }
 }
 
 extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t* act_dev, const uint16_t* h1_dev, const void* conv2_t_frag_dev,
@@ -1052,7 +1145,7 @@ extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t*
     if (!n_samples) return 0;
     DgradArgs a;
     a.d_act = d_act_dev; a.act = act_dev; a.h1 = h1_dev; a.w2t = (const u32x4_t*)conv2_t_frag_dev; a.dz2 = dz2_dev; a.dz1 = dz1_dev;
-    a.db2 = bias2_grad_dev; a.db1 = bias1_grad_dev; a.S = n_samples; a.Kp = ctf_policy_act_stride(grid_size, meta_len);
+    a.db2 = bias2_grad_dev; a.db1 = bias1_grad_dev; a.dw2 = nullptr; a.S = n_samples; a.Kp = ctf_policy_act_stride(grid_size, meta_len);
     const int G1 = grid_size - 2, G2 = grid_size - 4;
     a.inv_g1 = (65536 + G1 - 1) / G1;
     a.inv_g2 = (65536 + G2 - 1) / G2;
@@ -1076,11 +1169,11 @@ extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t*
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
     if (grid_size == 15) {
-        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<15>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        if (err == hipSuccess) hipLaunchKernelGGL(k_policy_front_dgrad<15>, dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<15, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<15, false>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
     } else {
-        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        if (err == hipSuccess) hipLaunchKernelGGL(k_policy_front_dgrad<11>, dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<11, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<11, false>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
     }
     if (err == hipSuccess) err = hipGetLastError();
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
@@ -1108,15 +1201,6 @@ struct WgradArgs {
     float* dw;               // float [CO][16][9] += (the caller zeroes it)
     int64_t S;
 };
-typedef short i16x4_t __attribute__((ext_vector_type(4)));
-// two transposed 4-position blocks (4 positions apart) -> one 8-position MFMA operand of this lane's channel
-__device__ __forceinline__ u32x4_t wgrad_tr_operand(const uint8_t* lds_addr, int second_block_bytes) {
-    typedef __attribute__((address_space(3))) i16x4_t* lds_v4;
-    const i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_addr));
-    const i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_addr + second_block_bytes));
-    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-    return (u32x4_t){l2[0], l2[1], h2[0], h2[1]};
-}
 // GO: side of the gradient image, GI = GO + 2: side of the activation image, CO: out channels (16 or 32)
 template <int GO, int CO, bool FROM_CODES>
 __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
@@ -1286,6 +1370,79 @@ extern "C" int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h
     } else {
         launch(k_policy_front_wgrad<7, 32, false>, 7, 32, a2);
         launch(k_policy_front_wgrad<9, 16, true>, 9, 16, a1);
+    }
+    if (err == hipSuccess) err = hipGetLastError();
+    if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err != hipSuccess) return pfail(hipGetErrorString(err));
+    return 0;
+}
+
+// The whole backward of the training front: conv2's data AND weight gradient in one pass (k_policy_front_dgrad<.., true>: dz2 never
+// leaves the CU), then conv1's weight gradient from the dz1 that pass wrote and the code bytes.
+extern "C" int ctf_policy_front_backward(const uint16_t* d_act_dev, const uint16_t* act_dev, const uint16_t* h1_dev, const uint8_t* codes_dev,
+                                         const void* conv2_t_frag_dev, int64_t n_samples, int32_t grid_size, int32_t meta_len,
+                                         uint16_t* dz1_dev, float* dw2_dev, float* dw1_dev, float* bias2_grad_dev, float* bias1_grad_dev,
+                                         int32_t device_id, void* stream) {
+    if (!d_act_dev || !act_dev || !h1_dev || !codes_dev || !conv2_t_frag_dev || !dz1_dev || !dw2_dev || !dw1_dev) return pfail("null argument");
+    if (grid_size != 15 && grid_size != 11) return pfail("the training front is built for grid_size 11 and 15 (the reference's maps)");
+    if (n_samples < 0) return pfail("n_samples out of range");
+    if (((uintptr_t)d_act_dev | (uintptr_t)act_dev) & 7) return pfail("8-byte alignment");
+    if (((uintptr_t)h1_dev | (uintptr_t)conv2_t_frag_dev | (uintptr_t)dz1_dev) & 15) return pfail("h1_dev / conv2_t_frag_dev / dz1_dev must be 16-byte aligned");
+    if (!n_samples) return 0;
+    DgradArgs a;
+    a.d_act = d_act_dev; a.act = act_dev; a.h1 = h1_dev; a.w2t = (const u32x4_t*)conv2_t_frag_dev; a.dz2 = nullptr; a.dz1 = dz1_dev;
+    a.db2 = bias2_grad_dev; a.db1 = bias1_grad_dev; a.dw2 = dw2_dev; a.S = n_samples; a.Kp = ctf_policy_act_stride(grid_size, meta_len);
+    const int G1 = grid_size - 2, G2 = grid_size - 4;
+    a.inv_g1 = (65536 + G1 - 1) / G1;
+    a.inv_g2 = (65536 + G2 - 1) / G2;
+    for (int p = 0; p < G1 * G1; p++)
+        if ((int)(((uint32_t)p * a.inv_g1) >> 16) != p / G1) return pfail("internal: reciprocal of G-2 not exact");
+    for (int p = 0; p < G2 * G2; p++)
+        if ((int)(((uint32_t)p * a.inv_g2) >> 16) != p / G2) return pfail("internal: reciprocal of G-4 not exact");
+    const int n_cus = policy_n_cus(device_id);
+    if (!n_cus) return pfail("hipGetDeviceProperties failed");
+    int dev_prev = 0;
+    if (hipGetDevice(&dev_prev) != hipSuccess) return pfail("hipGetDevice failed");
+    if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipSuccess;
+    {   // the fused pass: four waves per block, one block per CU (the padded images are 25 KB per wave, the registers one wave per SIMD)
+        const int wpb = 4;
+        const int ra = G2 + 1 + ((G2 & 1) ? 0 : 1);
+        const size_t per_wave = (size_t)4 * grid_size * 18 * 16 + (size_t)2 * (ra + 2) * 18 * 16;  // k_policy_front_dgrad<.., true>: ZB + 2 H1A
+        size_t sh = (size_t)wpb * per_wave;
+        const size_t red = (size_t)wpb * 9 * 32 * 16 * 4;
+        if (sh < red) sh = red;
+        int64_t blocks = (n_samples + wpb - 1) / wpb;
+        if (blocks > (int64_t)n_cus) blocks = n_cus;
+        if (grid_size == 15) {
+            err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<15, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<15, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+        } else {
+            err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<11, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<11, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+        }
+    }
+    {   // conv1's weight gradient (as in ctf_policy_front_wgrad)
+        const int wpb = 2, go = G1, co = 16;
+        const int ra = go + 1 + ((go & 1) ? 0 : 1), rb = ra + 2;
+        size_t sh = (size_t)wpb * ((size_t)ra * 16 * co * 2 + (size_t)rb * 18 * 32);
+        const size_t red = (size_t)wpb * 9 * co * 16 * 4;
+        if (sh < red) sh = red;
+        int per_cu = (int)((160 * 1024) / sh);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 4) per_cu = 4;
+        int64_t blocks = (n_samples + wpb - 1) / wpb;
+        if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
+        WgradArgs a1;
+        a1.grad = dz1_dev; a1.img = nullptr; a1.codes = codes_dev; a1.dw = dw1_dev; a1.S = n_samples;
+        if (grid_size == 15) {
+            if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_wgrad<13, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_wgrad<13, 16, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a1);
+        } else {
+            if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_wgrad<9, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_wgrad<9, 16, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a1);
+        }
     }
     if (err == hipSuccess) err = hipGetLastError();
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);

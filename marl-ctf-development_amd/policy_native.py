@@ -166,6 +166,7 @@ class _NativeFront(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, codes, meta, w1, b1, w2, b2):
         ctx.native_wgrad = bool(net.native_wgrad)
+        ctx.fused = bool(net.fused_backward)
         act, h0, h1 = net.features_train(codes, meta, want_h0=not ctx.native_wgrad)
         ctx.save_for_backward(act, h0 if h0 is not None else codes, h1, w2)
         ctx.geom = (net.grid_size, int(w1.shape[1]), net.metadata_size, net._ready()["lib"])
@@ -183,6 +184,16 @@ class _NativeFront(torch.autograd.Function):
         ptr = lambda t: C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         d_act = d_act.to(bf).contiguous()
+        if ctx.native_wgrad and ctx.fused:
+            # round 4: conv2's data AND weight gradient in one pass (dz2 never leaves the CU), then conv1's weight gradient from the dz1
+            # scratch that pass wrote and the code bytes (h0 here is the codes) — ctf_policy_front_backward
+            dz1 = torch.empty((b, g1, g1, 16), dtype=bf, device=dev)
+            grads = torch.zeros(48 + 32 * 16 * 9 + 16 * 16 * 9, dtype=torch.float32, device=dev)
+            db2, db1, dw2, dw1 = grads[:32], grads[32:48], grads[48:48 + 32 * 16 * 9], grads[48 + 32 * 16 * 9:]
+            if lib.ctf_policy_front_backward(ptr(d_act), ptr(act), ptr(h1), ptr(h0), ptr(ctx.f2t), b, g, m, ptr(dz1), ptr(dw2), ptr(dw1), ptr(db2),
+                                             ptr(db1), dev.index, stream) != 0:
+                raise _abi.CtfLibraryError("ctf_policy_front_backward: " + (lib.ctf_policy_last_error() or b"").decode())
+            return None, None, None, dw1.view(16, 16, 3, 3)[:, :c_in].contiguous(), db1, dw2.view(32, 16, 3, 3), db2
         # one launch: tanh' of conv2's output (rows of the activation matrix in, channels-last out), conv2's data gradient, tanh' of
         # conv1's output, both bias gradients in float32; the library is left with the two weight gradients
         dz2 = torch.empty((b, g2, g2, 32), dtype=bf, device=dev)
@@ -209,6 +220,7 @@ class _NativeFront(torch.autograd.Function):
 class CtfPolicyNative(CtfPolicy):
     native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
+    fused_backward = True   # ... conv2's weight gradient inside the data-gradient pass (ctf_policy_front_backward; False: three launches)
     factored_fc1 = os.environ.get("CTF_POLICY_FACT", "1") != "0"  # act_from_codes(shared_view=True): fc1 as one GEMM row per (env, view) + a per-agent patch product
                             # (ctf_policy_features_fact / ctf_policy_fc1_patch) instead of one activation row per agent
 

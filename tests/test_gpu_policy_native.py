@@ -519,3 +519,14 @@ def test_backward_kernels_of_the_conv_front_match_their_float64_definitions(g, c
     dw2_got, dw1_got = dw[:4608].double().reshape(32, 16, 9), dw[4608:].double().reshape(16, 16, 9)
     assert torch.allclose(dw2_got, dw2_want, rtol=1e-4, atol=1e-4 * float(dw2_want.abs().max()))
     assert torch.allclose(dw1_got[:, :c], dw1_want, rtol=1e-4, atol=1e-4 * float(dw1_want.abs().max())) and float(dw1_got[:, c:].abs().max()) == 0.0
+    # ---- round 4: the same backward as ONE call (conv2's weight gradient inside the data-gradient pass: dz2 never leaves the CU)
+    dz1_f = torch.empty((b, p1, 16), dtype=bf, device=dev)
+    db_f = torch.zeros(48, dtype=torch.float32, device=dev)
+    dw_f = torch.zeros(32 * 16 * 9 + 16 * 16 * 9, dtype=torch.float32, device=dev)
+    assert lib.ctf_policy_front_backward(ptr(d_act), ptr(act), ptr(h1), ptr(codes_t), ptr(f2t), b, g, m, ptr(dz1_f), ptr(dw_f[:4608]), ptr(dw_f[4608:]),
+                                         ptr(db_f[:32]), ptr(db_f[32:]), 0, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dz1_f, dz1)                                                      # the data path is the same arithmetic
+    assert torch.allclose(db_f, db, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(dw_f[:4608].double().reshape(32, 16, 9), dw2_want, rtol=1e-4, atol=1e-4 * float(dw2_want.abs().max()))
+    assert torch.allclose(dw_f[4608:].double().reshape(16, 16, 9)[:, :c], dw1_want, rtol=1e-4, atol=1e-4 * float(dw1_want.abs().max()))
