@@ -39,7 +39,8 @@ int32_t ctf_policy_act_stride(int32_t grid_size, int32_t meta_len);
  *   act_dev          bf16 [n_sel * n_envs][ctf_policy_act_stride()], 16-byte aligned.  Column of conv2 output channel c
  *                    at position p (row-major over (G-4)^2): ((c / 4) * PP + p) * 4 + c % 4; columns of positions
  *                    (G-4)^2 .. PP-1 hold finite don't-care values (give them zero weight); at 32 * PP the meta_len
- *                    metadata values; then don't-care padding.  (fc1.weight's columns are permuted to this order once.)
+ *                    metadata values; at 32 * PP + meta_len the constant 1.0 (a caller may keep fc1's bias in that column of
+ *                    its weight, else zero weight); then zeros.  (fc1.weight's columns are permuted to this order once.)
  *   shared_view_selfcell_dev   NULL, or uint16 [n_envs][n_agents] from ctf_observe_codes (the cell of every agent's bit 7)
  *                    together with the caller's guarantee that the selected agents see the same tile planes — same team
  *                    and same reverse flag (standardise_state relabels by team, gridworld_ctf.py:981-988), so that their

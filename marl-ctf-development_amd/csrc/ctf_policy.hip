@@ -147,9 +147,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 *(u32x4_t*)(h0 + H0A + c * 16) = (u32x4_t){w[4], w[5], w[6], w[7]};
             }
         }
-        // metadata: f16 -> bf16 pairs behind the conv features, zero padding to Kp
+        // metadata: f16 -> bf16 pairs behind the conv features; then ONE column of 1.0 (column 32 PP + M: a caller may keep fc1's bias
+        // in that column of its weight — the training path does, so that the bias gradient falls out of the weight-gradient GEMM; the
+        // inference weights hold zero there); zero padding to Kp
         if (lane < npair) {
-            uint32_t out = 0;
+            uint32_t out = lane == (a.M >> 1) ? 0x3F80u : 0u;
             if (lane < (a.M >> 1)) {
                 const float lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(two & 0xFFFFu));
                 const float hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(two >> 16));
@@ -499,8 +501,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             const uint32_t mw = k == 0 ? metaw[0] : k == 1 ? metaw[1] : k == 2 ? metaw[2] : metaw[3];
             const int syk = sc / G, sxk = sc - syk * G;
             uint8_t* const arow = act_env + k * agent_stride;
-            if (lane < npair) {  // metadata behind the conv features
-                uint32_t out = 0;
+            if (lane < npair) {  // metadata behind the conv features, then the column of 1.0 (see k_policy_features)
+                uint32_t out = lane == (a.M >> 1) ? 0x3F80u : 0u;
                 if (lane < (a.M >> 1)) {
                     const float lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(mw & 0xFFFFu));
                     const float hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(mw >> 16));

@@ -297,6 +297,11 @@ class CtfPolicyNative(CtfPolicy):
             maps = {k: torch.from_numpy(v).to(dev) for k, v in gather_maps(self.n_channels, self.n_actions).items()}
             maps.update(dev=dev, kp=len(order), col_src=torch.from_numpy(np.maximum(order, 0)).to(dev),
                         col_keep=torch.from_numpy((order >= 0).astype(np.float32)).to(dev))
+            one_col = np.zeros(len(order), np.float32)
+            pp = ((self.grid_size - 4) ** 2 + 31) // 32 * 32
+            one_col[32 * pp + self.metadata_size] = 1.0  # the column in which the front kernels write 1.0 (include/ctf_policy.h)
+            assert order[32 * pp + self.metadata_size] < 0
+            maps["one_col"] = torch.from_numpy(one_col).to(dev)
             if self.fact_supported():
                 maps["pf"] = torch.from_numpy(fc1_patch_map(self.grid_size, self.metadata_size)).to(dev)
             assert lib.ctf_policy_act_stride(self.grid_size, self.metadata_size) == len(order)
@@ -322,7 +327,7 @@ class CtfPolicyNative(CtfPolicy):
                 fc1_w=fc1.to(bf).contiguous(), fc1_b=(self.fc1.bias.float() * _TWO_LOG2E).to(bf),
                 t2=take(tail, m["t2"], _TWO_LOG2E, bf), tb2=take(tail, m["tb2"], _TWO_LOG2E, f32),
                 th=take(tail, m["th"], 1.0, bf), tbh=take(tail, m["tbh"], 1.0, f32),
-                col_src=m["col_src"], col_keep=m["col_keep"], f2t=take(w2, m["f2t"], 1.0, bf),
+                col_src=m["col_src"], col_keep=m["col_keep"], f2t=take(w2, m["f2t"], 1.0, bf), one_col=m["one_col"],
             )
             if "pf" in m:  # the factored fc1 path (ctf_policy_fc1_patch): W_flat in the view's column order, the per-position fragments, the bias
                 kv = lib.ctf_policy_fact_view_stride(self.grid_size)
@@ -462,8 +467,10 @@ class CtfPolicyNative(CtfPolicy):
         act = _NativeFront.apply(self, codes.contiguous(), metadata.to(torch.float16).contiguous(), self.conv1.weight, self.conv1.bias,
                                  self.conv2.weight, self.conv2.bias)
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            w = self.fc1.weight.index_select(1, p["col_src"]) * p["col_keep"]  # [256, Kp]: zero weight on the row's padding
-            x = torch.tanh(torch.nn.functional.linear(act, w, self.fc1.bias))
+            # [256, Kp]: zero weight on the row's padding, and the bias in the column where the front writes 1.0 — the bias gradient then
+            # falls out of the weight-gradient GEMM instead of a reduction over the batch of its own
+            w = self.fc1.weight.index_select(1, p["col_src"]) * p["col_keep"] + self.fc1.bias[:, None] * p["one_col"]
+            x = torch.tanh(torch.nn.functional.linear(act, w))
             x = torch.tanh(self.fc2(x))
             value, logits = self.value_head(x), self.action_head(x)
         return value.float(), logits.float()
