@@ -79,10 +79,12 @@ def _free_port():
 
 def visible_gpus():
     """How many HIP devices this box shows — asked of a CHILD process, so that the parent stays free of any HIP state (a process that
-    has touched the GPU must not start the ranks on this pool).  CTF_BENCH_DRYRUN ranks run on the CPU and need none."""
+    has touched the GPU must not start the ranks on this pool).  CTF_BENCH_DRYRUN ranks run on the CPU and need none;
+    CTF_BENCH_ONE_DEVICE=1 puts every rank on device 0 (a rehearsal of the N-rank path on a one-GPU box, over gloo: RCCL refuses two
+    ranks on one device)."""
     import subprocess
 
-    if os.environ.get("CTF_BENCH_DRYRUN"):
+    if os.environ.get("CTF_BENCH_DRYRUN") or os.environ.get("CTF_BENCH_ONE_DEVICE"):
         return None
     r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, text=True, timeout=600)
     try:
@@ -362,6 +364,8 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        if os.environ.get("CTF_BENCH_ONE_DEVICE"):  # rehearsal: N ranks on device 0 (gloo)
+            local_rank = 0
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
@@ -373,7 +377,7 @@ def main():
         import torch.distributed as dist
 
         single_rank_rendezvous()
-        if dryrun:
+        if dryrun or os.environ.get("CTF_BENCH_ONE_DEVICE"):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
@@ -424,6 +428,7 @@ def main():
                 "envs_per_gpu": E,
                 "global_envs": n_gpus * E,
                 "metrics_counters": not args.no_metrics,
+                "ranks_share_one_device": bool(os.environ.get("CTF_BENCH_ONE_DEVICE")),
                 "rollout_exchange": ("RCCL all-gather of rewards+done per 16-step chunk, async" if exchange else
                                      "none: env shards are independent (data-parallel learner)"),
             },

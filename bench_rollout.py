@@ -90,6 +90,7 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         "rollout_env_steps_per_s": world * envs * steps / rollout_s, "rollout_s": rollout_s,
         "policy_samples_per_sec": world * envs * steps * vec.N_AGENTS / rollout_s, "env_share_of_rollout_time": env_s / rollout_s,
         "rollout_bytes_per_gpu": int(sum(t.numel() * t.element_size() for t in out.values() if hasattr(t, "numel"))),
+        "ranks_share_one_device": bool(os.environ.get("CTF_BENCH_ONE_DEVICE")),
     }
     if update:
         import copy
@@ -199,7 +200,11 @@ def main():
         import torch.distributed as dist
 
         bench.single_rank_rendezvous()
-        if is_dry:
+        if os.environ.get("CTF_BENCH_ONE_DEVICE"):  # rehearsal of the N-rank iteration on a one-GPU box: every rank on device 0, gloo
+            local_rank = 0
+        if is_dry or os.environ.get("CTF_BENCH_ONE_DEVICE"):
+            if not is_dry:
+                torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
             if local_rank >= torch.cuda.device_count():

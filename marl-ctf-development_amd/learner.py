@@ -67,13 +67,26 @@ def calculate_advantages(next_value, rewards, next_done, dones, values, gamma=0.
     return advantages, returns
 
 
+def _via_host(t, group):
+    """gloo moves host memory: a device tensor goes through a host copy (the one-GPU rehearsal of the N-rank path runs over gloo, RCCL
+    refuses two ranks on one device); RCCL / gloo-on-CPU take the tensor as it is."""
+    import torch.distributed as dist
+
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def broadcast_module(module, src=0, group=None):
     """Every rank takes rank ``src``'s parameters of ``module`` (one flat broadcast)."""
     import torch.distributed as dist
 
     ps = list(module.parameters())
     flat = torch.cat([p.detach().reshape(-1) for p in ps])
-    dist.broadcast(flat, src=src, group=group)
+    if _via_host(flat, group):
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src, group=group)
     with torch.no_grad():
         off = 0
         for p in ps:
@@ -142,7 +155,12 @@ class PPOLearner:
         if self.dp:
             import torch.distributed as dist
 
-            dist.broadcast(seed, src=0, group=self.group)
+            if _via_host(seed, self.group):
+                host = seed.cpu()
+                dist.broadcast(host, src=0, group=self.group)
+                seed = host
+            else:
+                dist.broadcast(seed, src=0, group=self.group)
         gen = torch.Generator(device=device)
         gen.manual_seed(int(seed.item()))
         return torch.randperm(batch_size, generator=gen, device=device)
@@ -151,7 +169,12 @@ class PPOLearner:
         if self.dp:
             import torch.distributed as dist
 
-            dist.all_reduce(t, group=self.group)
+            if _via_host(t, self.group):
+                host = t.cpu()
+                dist.all_reduce(host, group=self.group)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, group=self.group)
         return t
 
     def _planes(self, grids):

@@ -266,6 +266,8 @@ def max_over_ranks(value, device, world):
     import torch
     import torch.distributed as dist
 
+    if dist.get_backend() == "gloo":
+        device = "cpu"  # (the one-GPU rehearsal runs N ranks over gloo: its collectives take host tensors)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
