@@ -161,6 +161,19 @@ struct FactFrontArgs {
     int32_t A, KV, KR;
 };
 
+// The next env's code bytes travel for a whole env: their four destination registers are PINNED (v156..v159, above what the kernel
+// otherwise needs) — left to the allocator they were moved mid-flight once h2s went over h0 and the pressure around the conv1 tail rose
+// (v_mov copies of registers whose loads had not landed: tools/isa_lint.py caught it before the kernel ever ran).
+__device__ __forceinline__ void fact_async_codes4(const uint8_t* cp, int lane, int GG, uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+    asm volatile("global_load_ubyte %0, %1, off" : "={v156}"(b0) : "v"(cp + min(lane, GG - 1)) : "memory");
+    asm volatile("global_load_ubyte %0, %1, off" : "={v157}"(b1) : "v"(cp + min(lane + WAVE, GG - 1)) : "memory");
+    asm volatile("global_load_ubyte %0, %1, off" : "={v158}"(b2) : "v"(cp + min(lane + 2 * WAVE, GG - 1)) : "memory");
+    asm volatile("global_load_ubyte %0, %1, off" : "={v159}"(b3) : "v"(cp + min(lane + 3 * WAVE, GG - 1)) : "memory");
+}
+__device__ __forceinline__ void fact_wait_codes4(uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+{v156}"(b0), "+{v157}"(b1), "+{v158}"(b2), "+{v159}"(b3) : : "memory");
+}
+
 // Per env, one wave:
 //   1. h0 <- the shared planes (only the cells whose code changed since the wave's previous env);
 //   2. shared conv1 -> tanh -> h1;
@@ -188,10 +201,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     constexpr int H2S = PP * H2R, HPB = 9 * 32;
     constexpr int H1B = (((G - 2) * (G - 2) + 15) / 16) * 16 * 32;
     constexpr int STAGE_REGION = (H1B + 4 * HPB) > 4 * PSTB ? (H1B + 4 * HPB) : 4 * PSTB;  // h1 ++ hp, later the staged patch rows
-    constexpr int PER_WAVE = G * G * 32 + H2S + STAGE_REGION;
+    constexpr int H0H2 = G * G * 32 > H2S ? G * G * 32 : H2S;  // h0, then (once the last conv1 operand has been read) h2s over it
+    constexpr int PER_WAVE = H0H2 + STAGE_REGION;
     uint8_t* h0 = (uint8_t*)lds + wave * PER_WAVE;
-    uint8_t* h2s = h0 + pol_h0_bytes(G);  // bf16 [PP positions][32 channels]: tanh(conv2) of the shared view
-    uint8_t* h1 = h2s + H2S;
+    uint8_t* h2s = h0;                    // bf16 [PP positions][32 channels]: tanh(conv2) of the shared view — written over h0, which is
+                                          // rebuilt from the code bytes for every env (two waves per SIMD are worth more than the
+                                          // incremental update of a persistent image: 1.25 -> 1.04 ms with the LDS this frees)
+    uint8_t* h1 = h0 + H0H2;
     uint8_t* hp = h1 + pol_h1_bytes(G);   // bf16 [4 agents][9 positions][16 channels]: tanh(conv1) on each agent's 3 x 3 patch
     uint8_t* pst = h1;                    // the env's patch rows [4][KR], staged over h1 / hp once the last operand has been read
     static_assert(STAGE_REGION >= 4 * PSTB && STAGE_REGION >= H1B + 4 * HPB, "h1 ++ hp and the staged patch rows share one region");
@@ -228,21 +244,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const int ag0 = (int)(a.sel_pack & 15u);
     const int mpairs = (fa.KR - 800) >> 1;  // dwords behind the 800 patch values: metadata pairs, then zeros
 
-    PolCodes<NP> oldc, nextc;
-#pragma unroll
-    for (int q = 0; q < NP; q++) oldc.b[q] = nextc.b[q] = 0;
-    {
-        const u32x4_t z = {0u, 0u, 0u, 0u};
-        for (int q = lane; q < GG * 2; q += WAVE) ((u32x4_t*)h0)[q] = z;
-        if (e_first < a.n_envs) nextc = pol_load_codes<NP>(a.codes + ((size_t)e_first * a.N + ag0) * GG, lane, GG);
+    static_assert(NP <= 4, "four pinned code registers");
+    uint32_t nc0 = 0, nc1 = 0, nc2 = 0, nc3 = 0;  // the next env's code bytes (cells lane, lane + 64, ...)
+    if (e_first < a.n_envs) {
+        const PolCodes<NP> first = pol_load_codes<NP>(a.codes + ((size_t)e_first * a.N + ag0) * GG, lane, GG);
+        nc0 = first.b[0];
+        if (NP > 1) nc1 = first.b[NP > 1 ? 1 : 0];
+        if (NP > 2) nc2 = first.b[NP > 2 ? 2 : 0];
+        if (NP > 3) nc3 = first.b[NP > 3 ? 3 : 0];
     }
 
     int trace_env = 0;
     (void)trace_env;
     for (int e = e_first; e < a.n_envs; e += e_stride, trace_env++) {
         FACT_STAMP(0);
-        const PolCodes<NP> cur = nextc;
-        nextc = pol_async_codes<NP>(a.codes + ((size_t)min(e + e_stride, a.n_envs - 1) * a.N + ag0) * GG, lane, GG);
+        PolCodes<NP> cur;
+        cur.b[0] = nc0;
+        if (NP > 1) cur.b[NP > 1 ? 1 : 0] = nc1;
+        if (NP > 2) cur.b[NP > 2 ? 2 : 0] = nc2;
+        if (NP > 3) cur.b[NP > 3 ? 3 : 0] = nc3;
+        fact_async_codes4(a.codes + ((size_t)min(e + e_stride, a.n_envs - 1) * a.N + ag0) * GG, lane, GG, nc0, nc1, nc2, nc3);
         uint32_t scw[4], metaw[4], slotw[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -252,18 +273,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             metaw[k] = pol_async_dword((const uint32_t*)(a.meta + row * a.M) + min(lane, (a.M >> 1) - 1));
             slotw[k] = pol_async_dword((const uint32_t*)fa.slot_of + (size_t)kk * a.n_envs + e);
         }
-        // ---- 1. h0 <- the shared planes (own-position bits stripped)
+        // ---- 1. h0 <- the shared planes (own-position bits stripped), from scratch: the previous env's h2s lies over it
+        {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < (GG * 2 + WAVE - 1) / WAVE; q++)
+                if (lane + WAVE * q < GG * 2) ((u32x4_t*)h0)[lane + WAVE * q] = z;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < NP; q++) {
             const int c = lane + WAVE * q;
-            const uint32_t o = oldc.b[q] & 0x7Fu, n = cur.b[q] & 0x7Fu;
-            if (c < GG && o != n) {
-                uint8_t* cellp = h0 + c * 16;
-                *(uint16_t*)(cellp + (o >> 3) * H0A + (o & 7u) * 2) = 0;
-                if (n) *(uint16_t*)(cellp + (n >> 3) * H0A + (n & 7u) * 2) = 0x3F80;
-            }
+            const uint32_t n = cur.b[q] & 0x7Fu;
+            if (c < GG && n) *(uint16_t*)(h0 + c * 16 + (n >> 3) * H0A + (n & 7u) * 2) = 0x3F80;
         }
-        oldc = cur;
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         FACT_STAMP(1);
@@ -320,7 +344,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                            "+v"(metaw[3]), "+v"(slotw[0]), "+v"(slotw[1]), "+v"(slotw[2]), "+v"(slotw[3])
                          :
                          : "memory");
-            pol_wait_codes<0, NP>(nextc);  // every register exactly once (see pol_wait_codes)
+            fact_wait_codes4(nc0, nc1, nc2, nc3);  // every register exactly once (see pol_wait_codes)
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
@@ -365,6 +389,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             }
         }
 
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // every lane's conv1 operands have been read: h2s may overwrite h0
+        __builtin_amdgcn_wave_barrier();
         FACT_STAMP(4);
         // ---- 3b. shared conv2 + tanh -> the env's ONE view row (all positions) and h2s
         uint8_t* const vrow = (uint8_t*)fa.view + (size_t)e * fa.KV * 2;
@@ -775,8 +801,9 @@ extern "C" int ctf_policy_features_fact(const uint8_t* codes_dev, const uint16_t
     const int pp = fa.KV / 32;
     const int h1hp = pol_h1_bytes(grid_size) + 4 * 9 * 32;
     const int pstb = 25 * 72 + 64;  // k_policy_features_fact's PSTB / H2R
-    const int per_wave = pol_h0_bytes(grid_size) + pp * 72 + (h1hp > 4 * pstb ? h1hp : 4 * pstb);
-    int wpb = 2;  // blocks of two waves, three per CU (LDS): 1.16-1.18 ms for the two teams of an arena step against 1.20-1.23 with 4 x 1
+    const int h0h2 = pol_h0_bytes(grid_size) > pp * 72 ? pol_h0_bytes(grid_size) : pp * 72;  // k_policy_features_fact's H0H2
+    const int per_wave = h0h2 + (h1hp > 4 * pstb ? h1hp : 4 * pstb);
+    int wpb = 4;  // two blocks of four waves per CU = two waves per SIMD (16.7 KB of LDS per wave since h2s lies over h0)
     if (const char* ov = getenv("CTF_POLICY_FACT_WPB")) {  // profiling only
         const int v = atoi(ov);
         if (v >= 1 && v <= 4) wpb = v;
