@@ -170,6 +170,18 @@ int ctf_policy_fc1_patch(const uint16_t* prow_dev, const int32_t* row_of_slot_de
                          const void* patch_frag_dev, const float* fc1_bias_dev, int32_t n_envs, int32_t n_sel, int32_t grid_size,
                          int32_t meta_len, uint16_t* y1_dev, int32_t device_id, void* stream);
 
+/* ctf_policy_fc1_patch with ctf_policy_head fused behind it: a tile of 128 slots is a tile of 128 samples of the network's tail, so
+ * fc1's pre-activation never goes to HBM — it is rounded to bf16 exactly as ctf_policy_fc1_patch stores it, and the tail runs on it in
+ * LDS.  Arguments: ctf_policy_fc1_patch's (without y1_dev) then ctf_policy_head's (without fc1_out_dev / n_samples; the sample index of
+ * every output, of mask_decision_dev / given_action_dev and of the Philox counter is the row k * n_envs + e).  Results are bit-identical
+ * to the two separate calls. */
+int ctf_policy_fc1_patch_head(const uint16_t* prow_dev, const int32_t* row_of_slot_dev, const int32_t* work_dev, const float* yview_dev,
+                              const void* patch_frag_dev, const float* fc1_bias_dev, int32_t n_envs, int32_t n_sel, int32_t grid_size,
+                              int32_t meta_len, const void* fc2_frag_dev, const float* fc2_bias_dev, const void* head_frag_dev,
+                              const float* head_bias_dev, const float* mask_decision_dev, const int32_t* given_action_dev,
+                              int32_t n_actions, uint64_t seed, uint64_t offset, int32_t* action_dev, float* logprob_dev,
+                              float* entropy_dev, float* value_dev, float* logits_dev, int32_t device_id, void* stream);
+
 const char* ctf_policy_last_error(void);
 
 #ifdef __cplusplus

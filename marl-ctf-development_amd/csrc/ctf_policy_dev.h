@@ -118,6 +118,154 @@ __device__ __forceinline__ void pol_wait_codes(PolCodes<NP>& c) {
 // the same wait for further registers (an s_waitcnt that follows one with the same count costs nothing)
 #define POL_WAIT_VM1(N, r0) asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(r0) : "n"(N) : "memory")
 
+// ---- the network's tail (k_policy_head, and fused behind k_policy_fc1_patch)
+#define HEAD_TILE 128
+#define HEAD_XS_ROW (256 * 2 + 16)
+#define HEAD_HS_ROW (128 * 2 + 16)
+struct HeadArgs {
+    const uint16_t* y1;       // bf16 [B][256]
+    const u32x4_t* fc2_frag;  // [4 M-tiles][16 K-steps][64]
+    const float* fc2_bias;    // [128] (scaled)
+    const u32x4_t* head_frag; // [4 K-steps][64]
+    const float* head_bias;   // [16]
+    const float* mask;        // [B] decision: 1 => only actions 0..4, or NULL
+    const int32_t* given;     // [B] actions to evaluate instead of sampling, or NULL
+    int32_t* action;          // [B]
+    float* logprob;           // [B]
+    float* entropy;           // [B]
+    float* value;             // [B]
+    float* logits;            // [B][A] raw logits, or NULL
+    int64_t B;
+    int32_t A;
+    uint64_t seed, offset;
+};
+
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+__device__ __forceinline__ float xlane(float v, int mask) { return __shfl_xor(v, mask, WAVE); }
+
+// Stages b-e of the head on a tile of 128 samples whose tanh(fc1) rows lie in `xs` (LDS, rows of HEAD_XS_ROW bytes; `hs` aliases it):
+// fc2, tanh, heads, mask, distribution, sampling.  `smp_of(r)` maps the tile's sample r to its global sample index (the Philox counter
+// and the row of every output), or a negative number for a slot that holds no sample.  Shared by k_policy_head (smp = tile * 128 + r)
+// and by k_policy_fc1_patch's fused epilogue (smp = the row of the tile's slot r).  Ends with every wave past its last LDS read of hs
+// except for the caller's own barrier.
+template <typename SmpOf>
+__device__ __forceinline__ void head_stages_bcde(const HeadArgs& a, uint8_t* xs, uint8_t* hs, const u32x4_t (&w2)[16], const u32x4_t (&wh)[4],
+                                                 const f32x16_t& bias2, const f32x4_t& biash, int wave, int lane, SmpOf smp_of) {
+    const int n32 = lane & 31, hh = lane >> 5, n16 = lane & 15, g4 = lane >> 4;
+    // ---- b. fc2: this wave's 32 channels x the tile's 128 samples
+    f32x16_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = bias2;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const u32x4_t b = *(const u32x4_t*)(xs + (32 * t + n32) * HEAD_XS_ROW + (2 * s + hh) * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(w2[s]), as_bf16x8(b), acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done reading xs: hs may overwrite it
+    // ---- c. tanh -> hs[sample][channel]
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32x2_t o;
+            o[0] = tanh2_pack(acc[t][4 * q], acc[t][4 * q + 1]);
+            o[1] = tanh2_pack(acc[t][4 * q + 2], acc[t][4 * q + 3]);
+            *(u32x2_t*)(hs + (32 * t + n32) * HEAD_HS_ROW + (32 * wave + 8 * q + 4 * hh) * 2) = o;
+        }
+    }
+    __syncthreads();
+    // ---- d. heads for this wave's 32 samples, e. distribution
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int r = 32 * wave + 16 * u + n16;
+        f32x4_t out = biash;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const u32x4_t b = *(const u32x4_t*)(hs + r * HEAD_HS_ROW + (4 * s + g4) * 16);
+            out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wh[s]), as_bf16x8(b), out, 0, 0, 0);
+        }
+        const int64_t smp = smp_of(r);
+        const bool live = smp >= 0;
+        const float dec = (a.mask && live) ? a.mask[smp] : 0.0f;
+        float l[4], mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = 4 * g4 + q;
+            // agent_network.py:71-75: decision 1 -> mask_5 (actions 0..4), decision 0 -> all ones, anything else -> the
+            // all-zero mask (every logit + -1e9: a uniform distribution in float32)
+            const bool off = (dec == 1.0f) ? (o >= 5) : (dec != 0.0f);
+            l[q] = (o < a.A) ? out[q] + (off ? -1e9f : 0.0f) : -INFINITY;
+            mx = fmaxf(mx, l[q]);
+        }
+        mx = fmaxf(mx, xlane(mx, 16));
+        mx = fmaxf(mx, xlane(mx, 32));
+        float e[4], part = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { e[q] = __expf(l[q] - mx); part += e[q]; }
+        float tot = part + xlane(part, 16);
+        tot += xlane(tot, 32);
+        const float logz = mx + __logf(tot);
+        float ent = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (4 * g4 + q < a.A) ent -= (e[q] / tot) * (l[q] - logz);
+        ent += xlane(ent, 16);
+        ent += xlane(ent, 32);
+        // inverse CDF over the outputs in index order: lanes g4 = 0..3 hold consecutive blocks of 4
+        const float p1 = xlane(part, 16), p2 = xlane(part, 32), p3 = xlane(p1, 32);  // partner sums: g4^1, g4^2, g4^3
+        float below = 0.0f;  // sum of the blocks with a smaller g4
+        if (g4 == 1) below = p1;            // block 0
+        else if (g4 == 2) below = p2 + p3;  // blocks 0 and 1
+        else if (g4 == 3) below = p1 + p2 + p3;
+        int act;
+        if (a.given) act = live ? a.given[smp] : 0;
+        else {
+            const float target = philox_uniform(a.seed, a.offset, (uint64_t)smp) * tot;
+            float c = below;
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { c += e[q]; cnt += (4 * g4 + q < a.A && c <= target) ? 1 : 0; }
+            cnt += __shfl_xor(cnt, 16, WAVE);
+            cnt += __shfl_xor(cnt, 32, WAVE);
+            const int last = (dec == 1.0f) ? min(4, a.A - 1) : a.A - 1;
+            act = min(cnt, last);
+        }
+        float lp = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (4 * g4 + q == act) lp = l[q] - logz;
+        lp += xlane(lp, 16);
+        lp += xlane(lp, 32);
+        if (live) {
+            if (g4 == 0) {
+                a.action[smp] = act;
+                a.logprob[smp] = lp;
+                a.entropy[smp] = ent;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int o = 4 * g4 + q;
+                if (o == a.A) a.value[smp] = out[q];
+                if (a.logits && o < a.A) a.logits[smp * a.A + o] = out[q];
+            }
+        }
+    }
+}
+
+
 // host-side helpers defined in ctf_policy.hip
 __attribute__((visibility("hidden"))) int ctf_policy_fail(const char* msg);      // sets ctf_policy_last_error(), returns -1
 __attribute__((visibility("hidden"))) int ctf_policy_cus(int device_id);          // compute units of a device (cached), 0 on error

@@ -539,8 +539,9 @@ struct PatchArgs {
     const u32x4_t* wfrag;        // bf16 fragments [P2 + 2 blocks][2 k-steps][8 n-tiles][64 lanes]: blocks 0..P2-1 = conv2 positions,
                                  // block P2 = zeros (a patch position outside the image), block P2 + 1 = the metadata columns
     const float* bias;           // f32 [256] (scaled)
-    uint16_t* y1;                // bf16 [A * E][256]
+    uint16_t* y1;                // bf16 [A * E][256] (HEAD instantiation: unused)
     int32_t E, KR;
+    HeadArgs head;               // HEAD instantiation: the network's tail runs on the tile while it is still in LDS (head.y1 / head.B unused)
 };
 
 // One block of four waves per tile of 128 slots; wave w owns the outputs 64 w .. 64 w + 63 (two 32-row A tiles) of all four 32-slot
@@ -560,13 +561,18 @@ struct PatchArgs {
 #ifndef FACT_RDEPTH
 #define FACT_RDEPTH 5   // the rows come from HBM (the front wrote them): fetched this many stages (0.43 us of MFMAs each) ahead
 #endif
-template <int TG>
+// HEAD = true: the tile of 128 slots IS a tile of 128 samples of the network's tail (k_policy_head), so fc1's pre-activation never goes
+// to HBM: the epilogue rounds it to bf16 exactly as the unfused path stores it, applies tanh and parks it in the tail's `xs` image, and
+// stages b-e of the tail (ctf_policy_dev.h) run on it in place, every output written to the row of its slot — bit-identical results.
+template <int TG, bool HEAD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_policy_fc1_patch(PatchArgs a) {
     constexpr int G = TG, G2 = G - 4, P2 = G2 * G2;
     constexpr int ROWB = 128 + FACT_ROW_PAD;      // bytes of a staged row: 64 k of one stage + padding
     constexpr int STAGEB = FACT_MT * ROWB;
     constexpr int KRB = FACT_NST * 128;
-    __shared__ __attribute__((aligned(16))) uint8_t stage[2 * STAGEB];
+    extern __shared__ __attribute__((aligned(16))) uint8_t patch_lds[];
+    uint8_t* const stage = patch_lds;             // [2 * STAGEB]; HEAD: then xs [128][HEAD_XS_ROW]
+    uint8_t* const xs = patch_lds + 2 * STAGEB;
     const int tile = blockIdx.x;
     if (tile >= *a.n_tiles) return;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -686,9 +692,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             u32x2_t o;
             o[0] = pack_bf16(d[0] + yv[m][i][0] + bs[0], d[1] + yv[m][i][1] + bs[1]);
             o[1] = pack_bf16(d[2] + yv[m][i][2] + bs[2], d[3] + yv[m][i][3] + bs[3]);
-            if (row >= 0 && !((FACT_PATCH_ABLATE & 4) && acc[0][m][0] != 12345.0f)) *(u32x2_t*)(a.y1 + (size_t)row * 256 + 4 * lane) = o;
+            if (HEAD) {  // tanh of the bf16-rounded pre-activation (what k_policy_head's stage a does to the stored y1), into the tail's image
+                u32x2_t x;
+                x[0] = tanh2_pack(__uint_as_float(o[0] << 16), __uint_as_float(o[0] & 0xFFFF0000u));
+                x[1] = tanh2_pack(__uint_as_float(o[1] << 16), __uint_as_float(o[1] & 0xFFFF0000u));
+                if (row < 0) x = (u32x2_t){0u, 0u};
+                *(u32x2_t*)(xs + (32 * m + wave + 4 * i) * HEAD_XS_ROW + lane * 8) = x;
+            } else if (row >= 0 && !((FACT_PATCH_ABLATE & 4) && acc[0][m][0] != 12345.0f)) {
+                *(u32x2_t*)(a.y1 + (size_t)row * 256 + 4 * lane) = o;
+            }
         }
         if (m < 3) __syncthreads();
+    }
+    if (HEAD) {
+        const HeadArgs& ha = a.head;
+        u32x4_t w2[16], wh[4];
+#pragma unroll
+        for (int s = 0; s < 16; s++) w2[s] = ha.fc2_frag[(wave * 16 + s) * WAVE + lane];
+#pragma unroll
+        for (int s = 0; s < 4; s++) wh[s] = ha.head_frag[s * WAVE + lane];
+        f32x16_t bias2;
+#pragma unroll
+        for (int r = 0; r < 16; r++) bias2[r] = ha.fc2_bias[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hh];
+        f32x4_t biash;
+#pragma unroll
+        for (int r = 0; r < 4; r++) biash[r] = ha.head_bias[4 * (lane >> 4) + r];
+        __syncthreads();  // xs is complete
+        const int32_t* slot_rows = a.row_of_slot + tile * FACT_MT;
+        head_stages_bcde(ha, xs, xs, w2, wh, bias2, biash, wave, lane, [&](int r) { return (int64_t)slot_rows[r]; });
     }
 }
 
@@ -849,9 +880,53 @@ extern "C" int ctf_policy_fc1_patch(const uint16_t* prow_dev, const int32_t* row
     DeviceScope scope(device_id);
     if (!scope.ok) return ctf_policy_fail("hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
-    if (grid_size == 15) hipLaunchKernelGGL(k_policy_fc1_patch<15>, dim3(t_max), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_policy_fc1_patch<11>, dim3(t_max), dim3(256), 0, st, a);
+    const int sh = 2 * FACT_MT * (128 + FACT_ROW_PAD);
+    if (grid_size == 15) hipLaunchKernelGGL((k_policy_fc1_patch<15, false>), dim3(t_max), dim3(256), sh, st, a);
+    else hipLaunchKernelGGL((k_policy_fc1_patch<11, false>), dim3(t_max), dim3(256), sh, st, a);
     const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
+    return 0;
+}
+
+extern "C" int ctf_policy_fc1_patch_head(const uint16_t* prow_dev, const int32_t* row_of_slot_dev, const int32_t* work_dev, const float* yview_dev,
+                                         const void* patch_frag_dev, const float* fc1_bias_dev, int32_t n_envs, int32_t n_sel, int32_t grid_size,
+                                         int32_t meta_len, const void* fc2_frag_dev, const float* fc2_bias_dev, const void* head_frag_dev,
+                                         const float* head_bias_dev, const float* mask_decision_dev, const int32_t* given_action_dev,
+                                         int32_t n_actions, uint64_t seed, uint64_t offset, int32_t* action_dev, float* logprob_dev,
+                                         float* entropy_dev, float* value_dev, float* logits_dev, int32_t device_id, void* stream) {
+    if (!prow_dev || !row_of_slot_dev || !work_dev || !yview_dev || !patch_frag_dev || !fc1_bias_dev || !fc2_frag_dev || !fc2_bias_dev || !head_frag_dev ||
+        !head_bias_dev || !action_dev || !logprob_dev || !entropy_dev || !value_dev)
+        return ctf_policy_fail("null argument");
+    int kv, kr;
+    if (fact_geometry(grid_size, meta_len, &kv, &kr)) return -1;
+    if (n_actions < 1 || n_actions > 15) return ctf_policy_fail("n_actions out of range");
+    if (((uintptr_t)prow_dev & 15) || ((uintptr_t)yview_dev & 15) || ((uintptr_t)patch_frag_dev & 15) || ((uintptr_t)fc1_bias_dev & 15) ||
+        ((uintptr_t)fc2_frag_dev & 15) || ((uintptr_t)head_frag_dev & 15))
+        return ctf_policy_fail("prow / yview / fragments / bias must be 16-byte aligned");
+    PatchArgs a;
+    a.prow = prow_dev; a.row_of_slot = row_of_slot_dev;
+    a.n_tiles = work_dev + 2 * FACT_BINS;
+    a.tile_cell = work_dev + 2 * FACT_BINS + 64;
+    a.yview = yview_dev; a.wfrag = (const u32x4_t*)patch_frag_dev; a.bias = fc1_bias_dev; a.y1 = nullptr;
+    a.E = n_envs; a.KR = kr;
+    HeadArgs& h = a.head;
+    h.y1 = nullptr; h.fc2_frag = (const u32x4_t*)fc2_frag_dev; h.fc2_bias = fc2_bias_dev; h.head_frag = (const u32x4_t*)head_frag_dev;
+    h.head_bias = head_bias_dev; h.mask = mask_decision_dev; h.given = given_action_dev; h.action = action_dev; h.logprob = logprob_dev;
+    h.entropy = entropy_dev; h.value = value_dev; h.logits = logits_dev; h.B = (int64_t)n_envs * n_sel; h.A = n_actions; h.seed = seed; h.offset = offset;
+    const int t_max = ctf_policy_fact_max_tiles(n_envs, n_sel, grid_size);
+    DeviceScope scope(device_id);
+    if (!scope.ok) return ctf_policy_fail("hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    const int sh = 2 * FACT_MT * (128 + FACT_ROW_PAD) + HEAD_TILE * HEAD_XS_ROW;
+    hipError_t err;
+    if (grid_size == 15) {
+        err = hipFuncSetAttribute((const void*)k_policy_fc1_patch<15, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+        if (err == hipSuccess) hipLaunchKernelGGL((k_policy_fc1_patch<15, true>), dim3(t_max), dim3(256), sh, st, a);
+    } else {
+        err = hipFuncSetAttribute((const void*)k_policy_fc1_patch<11, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+        if (err == hipSuccess) hipLaunchKernelGGL((k_policy_fc1_patch<11, true>), dim3(t_max), dim3(256), sh, st, a);
+    }
+    if (err == hipSuccess) err = hipGetLastError();
     if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
     return 0;
 }

@@ -220,6 +220,8 @@ class _NativeFront(torch.autograd.Function):
 class CtfPolicyNative(CtfPolicy):
     native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
+    fused_head = False      # the network's tail fused behind the patch product (ctf_policy_fc1_patch_head): bit-identical, and measured
+                            # no faster — 0.262 ms per call against 0.179 + 0.076 (the tail then runs at one block per CU) — so off
     fused_backward = True   # ... conv2's weight gradient inside the data-gradient pass (ctf_policy_front_backward; False: three launches)
     factored_fc1 = os.environ.get("CTF_POLICY_FACT", "1") != "0"  # act_from_codes(shared_view=True): fc1 as one GEMM row per (env, view) + a per-agent patch product
                             # (ctf_policy_features_fact / ctf_policy_fc1_patch) instead of one activation row per agent
@@ -406,6 +408,12 @@ class CtfPolicyNative(CtfPolicy):
         """fc1's scaled pre-activation (bf16 [len(agent_idx) * E, 256], what ctf_policy_head consumes) for agents that SHARE A VIEW, without
         the per-agent activation matrix: bucket by own cell, conv front -> view rows + patch rows, one GEMM over the E view rows, the
         per-agent patch product."""
+        return self._fact_run(codes, meta, agent_idx, self_cells, None)
+
+    def _fact_run(self, codes, meta, agent_idx, self_cells, head):
+        """The factored path up to the patch product; ``head`` = None: -> y1 (ctf_policy_fc1_patch); ``head`` = dict(mask=, given=,
+        want_logits=): the network's tail fused behind the patch product (ctf_policy_fc1_patch_head) -> (action, logprob, entropy, value,
+        logits or None)."""
         p = self._ready()
         lib = p["lib"]
         E, N = int(codes.shape[0]), int(codes.shape[1])
@@ -431,9 +439,60 @@ class CtfPolicyNative(CtfPolicy):
 
         ok(lib.ctf_policy_fact_bucket(ptr(self_cells), E, N, G, sel_arr, A, ptr(b["work"]), ptr(b["slot_of"]), ptr(b["row_of_slot"]),
                                       dev.index, stream), "ctf_policy_fact_bucket")
-        ok(lib.ctf_policy_features_fact(ptr(codes), ptr(meta), ptr(self_cells), E, N, G, M, sel_arr, A, ptr(p["f1"]), ptr(p["b1"]), ptr(p["f2"]),
-                                        ptr(p["b2"]), ptr(b["slot_of"]), ptr(b["view"]), ptr(b["prow"]), dev.index, stream), "ctf_policy_features_fact")
-        torch.mm(b["view"], p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"])  # float32 out: the patch product is added before the one rounding
+
+        def front_and_gemm(view):
+            ok(lib.ctf_policy_features_fact(ptr(codes), ptr(meta), ptr(self_cells), E, N, G, M, sel_arr, A, ptr(p["f1"]), ptr(p["b1"]), ptr(p["f2"]),
+                                            ptr(p["b2"]), ptr(b["slot_of"]), ptr(view), ptr(b["prow"]), dev.index, stream), "ctf_policy_features_fact")
+            torch.mm(view, p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"])  # float32 out: the patch product is added before the one rounding
+
+        if not b.get("placed"):
+            # Large allocations on this pool come in two kinds: the slow one costs the front's stores and the GEMM's reads
+            # of the view matrix ~25 % (0.22 against 0.16 ms for the GEMM of a 65 536-env step).  Once per buffer: candidates are timed
+            # with the real work, a loser goes back to the driver at once (two held at most), until both kinds were seen or 8 tries.
+            b["placed"] = True
+            if b["view"].numel() * 2 > (256 << 20):
+                def probe(view):
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    front_and_gemm(view)
+                    t0.record()
+                    for _ in range(2):
+                        front_and_gemm(view)
+                    t1.record()
+                    t1.synchronize()
+                    return t0.elapsed_time(t1) / 2
+                times = [probe(b["view"])]
+                while len(times) < 8 and max(times) < 1.08 * min(times):
+                    try:
+                        cand = torch.empty_like(b["view"])
+                    except torch.cuda.OutOfMemoryError:
+                        break
+                    times.append(probe(cand))
+                    if times[-1] < min(times[:-1]):
+                        b["view"] = cand
+                    del cand
+                    torch.cuda.empty_cache()
+                self.placement_probe_ms = times
+        front_and_gemm(b["view"])
+        if head is not None:
+            B = A * E
+            f32 = dict(dtype=torch.float32, device=dev)
+            action = torch.empty(B, dtype=torch.int32, device=dev)
+            logprob, entropy, value = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32)
+            logits = torch.empty((B, self.n_actions), **f32) if head.get("want_logits") else None
+            mask, given = head.get("mask"), head.get("given")
+            if mask is not None:
+                mask = mask.reshape(-1).to(torch.float32).contiguous()
+                if mask.numel() != B:
+                    raise ValueError("masking_decision_tensor must have one entry per sample")
+            if given is not None:
+                given = given.reshape(-1).to(torch.int32).contiguous()
+            self._calls += 1
+            optr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            ok(lib.ctf_policy_fc1_patch_head(ptr(b["prow"]), ptr(b["row_of_slot"]), ptr(b["work"]), ptr(b["yview"]), ptr(p["pf"]), ptr(p["fc1_b32"]),
+                                             E, A, G, M, ptr(p["t2"]), ptr(p["tb2"]), ptr(p["th"]), ptr(p["tbh"]), optr(mask), optr(given),
+                                             self.n_actions, C.c_uint64(self._seed), C.c_uint64(self._calls), ptr(action), ptr(logprob),
+                                             ptr(entropy), ptr(value), optr(logits), dev.index, stream), "ctf_policy_fc1_patch_head")
+            return action, logprob, entropy, value, logits
         ok(lib.ctf_policy_fc1_patch(ptr(b["prow"]), ptr(b["row_of_slot"]), ptr(b["work"]), ptr(b["yview"]), ptr(p["pf"]), ptr(p["fc1_b32"]),
                                     E, A, G, M, ptr(b["y1"]), dev.index, stream), "ctf_policy_fc1_patch")
         return b["y1"]
@@ -558,8 +617,11 @@ class CtfPolicyNative(CtfPolicy):
         Philox4x32-10 uniform per sample, keyed by this module's seed and call count."""
         n_sel = len(agent_idx)
         if shared_view and self.factored_fc1 and self_cells is not None and n_sel <= 4 and self.fact_supported():
-            y1 = self.fc1_from_codes_factored(codes, meta, agent_idx, self_cells)
-            act, logprob, entropy, value, _ = self._head(y1, mask=masking_decision_tensor, given=action)
+            if self.fused_head:  # the network's tail behind the patch product, fc1's output never in HBM (bit-identical to the two calls)
+                act, logprob, entropy, value, _ = self._fact_run(codes, meta, agent_idx, self_cells, dict(mask=masking_decision_tensor, given=action))
+            else:
+                y1 = self.fc1_from_codes_factored(codes, meta, agent_idx, self_cells)
+                act, logprob, entropy, value, _ = self._head(y1, mask=masking_decision_tensor, given=action)
         else:
             feats = self._features_tuned(codes, meta, agent_idx, shared_view, self_cells)
             act, logprob, entropy, value, _ = self._tail(feats, mask=masking_decision_tensor, given=action)

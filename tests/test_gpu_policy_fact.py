@@ -211,3 +211,26 @@ def test_full_size_factored_fc1_is_run_to_run_identical_and_agrees_with_a_small_
     # rounding flip, or a few spacings where the terms cancel to a small value)
     a, b = small.reshape(4, 512, 256).double(), first.reshape(4, e, 256)[:, :512].double()
     assert bool(((a - b).abs() <= ulp_bf16(b) + 4e-3).all()) and float(((a - b).abs() > 0).double().mean()) < 0.02
+
+
+def test_the_fused_tail_gives_the_separate_calls_results_bit_for_bit():
+    """ctf_policy_fc1_patch_head (the network's tail on the tile while it is in LDS) against ctf_policy_fc1_patch + ctf_policy_head:
+    sampled actions (same Philox key and counter), log-probs, entropies, values and logits are identical; given actions too."""
+    rng = np.random.default_rng(77)
+    g, c, n, e = 15, 14, 8, 1500
+    sel = [1, 3, 5, 7]
+    codes, cells = team_codes(rng, e, n, g, c)
+    metas = rng.random((e, n, 22)).astype(np.float16)
+    net = fill_(native.CtfPolicyNative(9, c, g, 22, seed=4242)).cuda()
+    dev = lambda a: torch.tensor(a, device="cuda")
+    dc, dm, ds = dev(codes), dev(metas), dev(cells)
+    mask = torch.tensor(rng.integers(0, 2, len(sel) * e).astype(np.float32), device="cuda")
+    for given in (None, torch.tensor(rng.integers(0, 5, len(sel) * e).astype(np.int32), device="cuda")):
+        net._calls = 10
+        y1 = net.fc1_from_codes_factored(dc, dm, sel, ds)
+        want = net._head(y1, mask=mask, given=given, want_logits=True)
+        net._calls = 10
+        got = net._fact_run(dc, dm, sel, ds, dict(mask=mask, given=given, want_logits=True))
+        for a, b, name in zip(got, want, ("action", "logprob", "entropy", "value", "logits")):
+            assert torch.equal(a, b), name
+    assert bool((got[0][mask == 1] < 5).all())
