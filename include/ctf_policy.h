@@ -98,6 +98,15 @@ int ctf_policy_front_backward(const uint16_t* d_act_dev, const uint16_t* act_dev
                               float* dw2_dev, float* dw1_dev, float* bias2_grad_dev, float* bias1_grad_dev, int32_t device_id,
                               void* stream);
 
+/* The weight and bias gradients of the small dense layers in the learner's backward (fc2: Linear(256, 128), agent_network.py:16; the two
+ * heads as one Linear(128, 16): rows 0..A-1 the action head, row A the value head, the rest zero, :17-18):
+ *     dw[n][k] += sum over samples of dy[m][n] * x[m][k]        db[n] += sum over samples of dy[m][n]      (the caller zeroes dw / db)
+ *   dy_dev bf16 [n_samples][n_out], x_dev bf16 [n_samples][n_in], both 16-byte aligned; (n_out, n_in) = (128, 256) or (16, 128);
+ *   dw_dev float [n_out][n_in]; db_dev float [n_out] or NULL.
+ * One pass over dy and x (HBM-bound) in place of the library's GEMM with a 128 x 256 output and K = n_samples plus a column reduction. */
+int ctf_policy_linear_wgrad(const uint16_t* dy_dev, const uint16_t* x_dev, int64_t n_samples, int32_t n_out, int32_t n_in, float* dw_dev,
+                            float* db_dev, int32_t device_id, void* stream);
+
 /* The rest of Agent.get_action_and_value (agent_network.py:37-40, 63-81) in one kernel:
  *   x = tanh(fc1 out); x = tanh(fc2(x)); value = value_head(x); logits = action_head(x)
  *   logits += (mask - 1) * 1e9 with mask = [1]*5 + [0]*(A-5) where the decision is 1, all ones otherwise

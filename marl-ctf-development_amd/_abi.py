@@ -145,6 +145,7 @@ SYMBOLS = {
     "ctf_policy_front_dgrad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "ctf_policy_front_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
     "ctf_policy_front_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "ctf_policy_linear_wgrad": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
     "ctf_policy_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P,
                                   C.c_int32, _P]),
     "ctf_policy_fact_view_stride": (C.c_int32, [C.c_int32]),

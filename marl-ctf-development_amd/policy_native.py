@@ -217,11 +217,42 @@ class _NativeFront(torch.autograd.Function):
         return None, None, None, dw1[:, :c_in].float(), db1, dw2.float(), db2
 
 
+class _TailLinear(torch.autograd.Function):
+    """y = x @ w^T + b for the small dense layers of a TRAINING step (fc2; the two heads as one 16-output layer), bf16 operands.  The
+    forward and the data gradient are the library's GEMMs (small K, fine); the weight and bias gradients — reductions over up to a
+    million samples into a few thousand numbers, which the library runs at 2 % of either roof — are ctf_policy_linear_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lib):
+        bf = torch.bfloat16
+        x = x.to(bf).contiguous()
+        wb = w.to(bf)
+        ctx.save_for_backward(x, wb)
+        ctx.lib = lib
+        return torch.nn.functional.linear(x, wb, b.to(bf))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        dy = dy.to(torch.bfloat16).contiguous()
+        dev = dy.device
+        n_out, n_in = wb.shape
+        grads = torch.zeros(n_out * n_in + n_out, dtype=torch.float32, device=dev)
+        dw, db = grads[:n_out * n_in], grads[n_out * n_in:]
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        if ctx.lib.ctf_policy_linear_wgrad(ptr(dy), ptr(x), dy.shape[0], n_out, n_in, ptr(dw), ptr(db), dev.index,
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) != 0:
+            raise _abi.CtfLibraryError("ctf_policy_linear_wgrad: " + (ctx.lib.ctf_policy_last_error() or b"").decode())
+        dx = torch.mm(dy, wb) if ctx.needs_input_grad[0] else None
+        return dx, dw.view(n_out, n_in), db, None
+
+
 class CtfPolicyNative(CtfPolicy):
     native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
     fused_head = False      # the network's tail fused behind the patch product (ctf_policy_fc1_patch_head): bit-identical, and measured
                             # no faster — 0.262 ms per call against 0.179 + 0.076 (the tail then runs at one block per CU) — so off
+    native_tail_wgrad = True  # fc2's and the heads' weight / bias gradients by ctf_policy_linear_wgrad (False: the library's GEMMs + reductions)
     fused_backward = True   # ... conv2's weight gradient inside the data-gradient pass (ctf_policy_front_backward; False: three launches)
     factored_fc1 = os.environ.get("CTF_POLICY_FACT", "1") != "0"  # act_from_codes(shared_view=True): fc1 as one GEMM row per (env, view) + a per-agent patch product
                             # (ctf_policy_features_fact / ctf_policy_fc1_patch) instead of one activation row per agent
@@ -530,8 +561,17 @@ class CtfPolicyNative(CtfPolicy):
             # falls out of the weight-gradient GEMM instead of a reduction over the batch of its own
             w = self.fc1.weight.index_select(1, p["col_src"]) * p["col_keep"] + self.fc1.bias[:, None] * p["one_col"]
             x = torch.tanh(torch.nn.functional.linear(act, w))
-            x = torch.tanh(self.fc2(x))
-            value, logits = self.value_head(x), self.action_head(x)
+            if self.native_tail_wgrad and self.fc2.weight.shape == (128, 256) and self.n_actions < 16:
+                # fc2 and the two heads (as ONE 16-output layer) with native weight / bias gradients (_TailLinear)
+                x = torch.tanh(_TailLinear.apply(x, self.fc2.weight, self.fc2.bias, p["lib"]))
+                pad = 16 - self.n_actions - 1
+                wh = torch.cat((self.action_head.weight, self.value_head.weight, self.action_head.weight.new_zeros((pad, 128))))
+                bh = torch.cat((self.action_head.bias, self.value_head.bias, self.action_head.bias.new_zeros(pad)))
+                y = _TailLinear.apply(x, wh, bh, p["lib"])
+                logits, value = y[:, :self.n_actions], y[:, self.n_actions:self.n_actions + 1]
+            else:
+                x = torch.tanh(self.fc2(x))
+                value, logits = self.value_head(x), self.action_head(x)
         return value.float(), logits.float()
 
     def _features_tuned(self, codes, meta, agent_idx, shared_view, self_cells, tries=12, slow_over_fast=1.1):

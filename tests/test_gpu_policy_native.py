@@ -530,3 +530,50 @@ def test_backward_kernels_of_the_conv_front_match_their_float64_definitions(g, c
     assert torch.allclose(db_f, db, rtol=1e-5, atol=1e-4)
     assert torch.allclose(dw_f[:4608].double().reshape(32, 16, 9), dw2_want, rtol=1e-4, atol=1e-4 * float(dw2_want.abs().max()))
     assert torch.allclose(dw_f[4608:].double().reshape(16, 16, 9)[:, :c], dw1_want, rtol=1e-4, atol=1e-4 * float(dw1_want.abs().max()))
+
+
+@pytest.mark.parametrize("n_out,n_in,m", [(128, 256, 5000), (16, 128, 777), (128, 256, 64), (16, 128, 131072)])
+def test_small_layer_weight_and_bias_gradients_match_float64(n_out, n_in, m):
+    """ctf_policy_linear_wgrad: dw = dy^T x and db = sum(dy) over the samples, bf16 operands, float32 accumulation (atomics across
+    blocks), against the float64 sums of the same bf16 values; added to what the buffers held."""
+    import ctypes as C
+
+    abi = importlib.import_module("marl-ctf-development_amd._abi")
+    lib = abi.load_library()
+    g = torch.Generator(device="cuda").manual_seed(n_out + m)
+    dy = (torch.randn((m, n_out), generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+    x = torch.tanh(torch.randn((m, n_in), generator=g, device="cuda")).to(torch.bfloat16)
+    dw = torch.full((n_out, n_in), 0.5, dtype=torch.float32, device="cuda")
+    db = torch.full((n_out,), -2.0, dtype=torch.float32, device="cuda")
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.ctf_policy_linear_wgrad(ptr(dy), ptr(x), m, n_out, n_in, ptr(dw), ptr(db), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    want_w = dy.double().T @ x.double() + 0.5
+    want_b = dy.double().sum(0) - 2.0
+    scale = float(want_w.abs().max())
+    assert float((dw.double() - want_w).abs().max()) < 1e-5 * max(scale, 1.0) * (1 + m / 65536)
+    assert float((db.double() - want_b).abs().max()) < 1e-5 * max(float(want_b.abs().max()), 1.0) * (1 + m / 65536)
+    assert lib.ctf_policy_linear_wgrad(ptr(dy), ptr(x), m, 64, 64, ptr(dw), ptr(db), 0, None) != 0  # an unsupported shape says so
+
+
+def test_native_tail_gradients_equal_the_library_paths():
+    """CtfPolicyNative.trunk_codes with native_tail_wgrad: outputs identical, gradients of fc2 and both heads (weights and biases) equal
+    to the library path's up to bf16 / summation-order effects."""
+    import copy
+
+    rng = np.random.default_rng(3)
+    g, c, n, b = 15, 14, 8, 3000
+    m = 2 * n + 6
+    codes = torch.tensor((rng.integers(0, c, (b, g, g)) * (rng.random((b, g, g)) < 0.3)).astype(np.uint8), device="cuda")
+    meta = torch.tensor(rng.random((b, m)).astype(np.float32), device="cuda")
+    base = fill_(native.CtfPolicyNative(9, c, g, m)).cuda()
+    outs = []
+    for flag in (True, False):
+        net = copy.deepcopy(base)
+        net.native_tail_wgrad = flag
+        value, logits = net.trunk_codes(codes, meta)
+        ((logits * torch.linspace(-1, 1, 9, device="cuda")).sum() + (value ** 2).sum()).backward()
+        outs.append((value.detach(), logits.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        a, bgrad = outs[0][2][k].double(), outs[1][2][k].double()
+        assert float((a - bgrad).abs().max()) <= 2e-2 * max(float(bgrad.abs().max()), 1e-6), (k, float((a - bgrad).abs().max()), float(bgrad.abs().max()))
