@@ -22,10 +22,11 @@ __device__ __forceinline__ u32x4_t tail_tr_operand(const uint8_t* lds_addr, int 
 
 struct TailWgradArgs {
     const uint16_t* dy;   // bf16 [M][N]
-    const uint16_t* x;    // bf16 [M][K]
-    float* dw;            // float [N][K] +=
+    const uint16_t* x;    // bf16 [M][x_stride]: the kernel's K columns start at column k_base + slab * K
+    float* dw;            // float [N][dw_stride] += (same column offset)
     float* db;            // float [N] +=, or NULL
     int64_t M;
+    int32_t x_stride, dw_stride, k_base, n_slabs;  // n_slabs > 1 (fc1): block b works on column slab b % n_slabs, sample range b / n_slabs
 };
 
 #define TAIL_CH 64     // samples per chunk (two K-steps of 32)
@@ -58,6 +59,8 @@ __global__ void __launch_bounds__(256) k_tail_wgrad(TailWgradArgs a) {
     const int kg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
     const int ra = (8 * kg + tq) * RA + tp * 8, rb = (8 * kg + tq) * RB + tp * 8;
     const int64_t n_chunks = (a.M + TAIL_CH - 1) / TAIL_CH;
+    const int slab = blockIdx.x % a.n_slabs, c_first = blockIdx.x / a.n_slabs, c_stride = gridDim.x / a.n_slabs;
+    const int kcol = a.k_base + slab * K;  // first column of x / dw this block works on
     u32x4_t pa[IA], pb[IB];
     auto fetch = [&](int64_t c) {
         const int64_t m0 = c * TAIL_CH;
@@ -71,12 +74,12 @@ __global__ void __launch_bounds__(256) k_tail_wgrad(TailWgradArgs a) {
         for (int i = 0; i < IB; i++) {
             const int idx = tid + 256 * i, row = idx / PB, oct = idx - row * PB;
             const int64_t m = m0 + row;
-            pb[i] = (idx < TAIL_CH * PB && m < a.M) ? *(const u32x4_t*)(a.x + (size_t)m * K + oct * 8) : (u32x4_t){0u, 0u, 0u, 0u};
+            pb[i] = (idx < TAIL_CH * PB && m < a.M) ? *(const u32x4_t*)(a.x + (size_t)m * a.x_stride + kcol + oct * 8) : (u32x4_t){0u, 0u, 0u, 0u};
         }
     };
-    int64_t c = blockIdx.x;
+    int64_t c = c_first;
     if (c < n_chunks) fetch(c);
-    for (; c < n_chunks; c += gridDim.x) {
+    for (; c < n_chunks; c += c_stride) {
 #pragma unroll
         for (int i = 0; i < IA; i++) {
             const int idx = tid + 256 * i, row = idx / PA, oct = idx - row * PA;
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(256) k_tail_wgrad(TailWgradArgs a) {
             const int idx = tid + 256 * i, row = idx / PB, oct = idx - row * PB;
             if (idx < TAIL_CH * PB) *(u32x4_t*)(B + row * RB + oct * 16) = pb[i];
         }
-        if (c + gridDim.x < n_chunks) fetch(c + gridDim.x);  // the next chunk travels while this one is contracted
+        if (c + c_stride < n_chunks) fetch(c + c_stride);  // the next chunk travels while this one is contracted
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < TAIL_CH / 32; ks++) {
@@ -118,7 +121,8 @@ __global__ void __launch_bounds__(256) k_tail_wgrad(TailWgradArgs a) {
 #pragma unroll
         for (int j = 0; j < WK; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(a.dw + (size_t)(16 * (n0 + i) + 4 * (lane >> 4) + r) * K + 16 * (k0 + j) + (lane & 15), acc[i][j][r]);
+            for (int r = 0; r < 4; r++)
+                atomicAdd(a.dw + (size_t)(16 * (n0 + i) + 4 * (lane >> 4) + r) * a.dw_stride + kcol + 16 * (k0 + j) + (lane & 15), acc[i][j][r]);
     if (a.db) {  // a thread's eight columns: octet tid % PA; the block's partial sums meet in LDS, one atomic per column and block
         float* red = (float*)tail_lds;
         __syncthreads();
@@ -145,21 +149,36 @@ extern "C" int ctf_policy_linear_wgrad(const uint16_t* dy_dev, const uint16_t* x
     if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return ctf_policy_fail("hipSetDevice failed");
     TailWgradArgs a;
     a.dy = dy_dev; a.x = x_dev; a.dw = dw_dev; a.db = db_dev; a.M = n_samples;
+    a.x_stride = n_in; a.dw_stride = n_in; a.k_base = 0; a.n_slabs = 1;
     const int64_t n_chunks = (n_samples + TAIL_CH - 1) / TAIL_CH;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
-    auto launch = [&](auto kernel, int n, int k, int per_cu) {
+    auto launch = [&](auto kernel, int n, int k, int64_t blocks) {
         const size_t sh = (size_t)TAIL_CH * (n * 2 + TAIL_PAD) + (size_t)TAIL_CH * (k * 2 + TAIL_PAD);
-        int64_t blocks = n_chunks < (int64_t)n_cus * per_cu ? n_chunks : (int64_t)n_cus * per_cu;
-        if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (err == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), sh, st, a);
     };
-    if (n_out == 128 && n_in == 256) launch(k_tail_wgrad<8, 16>, 128, 256, 2);       // fc2
-    else if (n_out == 16 && n_in == 128) launch(k_tail_wgrad<1, 8>, 16, 128, 4);      // the two heads, padded to 16 outputs
-    else err = hipErrorInvalidValue;
+    auto capped = [&](int per_cu) { return n_chunks < (int64_t)n_cus * per_cu ? n_chunks : (int64_t)n_cus * per_cu; };
+    if (n_out == 128 && n_in == 256) launch(k_tail_wgrad<8, 16>, 128, 256, capped(2));       // fc2
+    else if (n_out == 16 && n_in == 128) launch(k_tail_wgrad<1, 8>, 16, 128, capped(4));      // the two heads, padded to 16 outputs
+    else if (n_out == 256 && n_in % 64 == 0 && n_in >= 128 && db_dev == nullptr) {
+        // fc1: every block takes all 256 outputs of a SLAB of 128 input columns over a range of the samples — x (the big operand, 8 KB per
+        // sample) is read exactly once, dy (512 B per sample) once per slab, by blocks that run side by side (slab = block % n_slabs);
+        // a remainder of 64 columns gets a launch of its own
+        const int slabs = n_in / 128;
+        int64_t ranges = ((int64_t)n_cus * 2 + slabs - 1) / slabs;
+        if (ranges > n_chunks) ranges = n_chunks;
+        if (ranges < 1) ranges = 1;
+        a.n_slabs = slabs;
+        launch(k_tail_wgrad<16, 8>, 256, 128, ranges * slabs);
+        if (n_in % 128) {
+            a.k_base = slabs * 128; a.n_slabs = 1;
+            launch(k_tail_wgrad<16, 4>, 256, 64, capped(1) < 64 ? capped(1) : 64);
+        }
+    } else err = hipErrorInvalidValue;
     if (err == hipSuccess) err = hipGetLastError();
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
-    if (err == hipErrorInvalidValue) return ctf_policy_fail("ctf_policy_linear_wgrad is built for (n_out, n_in) = (128, 256) and (16, 128)");
+    if (err == hipErrorInvalidValue) return ctf_policy_fail("ctf_policy_linear_wgrad is built for (n_out, n_in) = (128, 256), (16, 128) and (256, a multiple of 64 without bias)");
     if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
     return 0;
 }

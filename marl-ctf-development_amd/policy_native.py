@@ -228,8 +228,8 @@ class _TailLinear(torch.autograd.Function):
         x = x.to(bf).contiguous()
         wb = w.to(bf)
         ctx.save_for_backward(x, wb)
-        ctx.lib = lib
-        return torch.nn.functional.linear(x, wb, b.to(bf))
+        ctx.lib, ctx.has_bias = lib, b is not None
+        return torch.nn.functional.linear(x, wb, None if b is None else b.to(bf))
 
     @staticmethod
     def backward(ctx, dy):
@@ -238,8 +238,8 @@ class _TailLinear(torch.autograd.Function):
         dev = dy.device
         n_out, n_in = wb.shape
         grads = torch.zeros(n_out * n_in + n_out, dtype=torch.float32, device=dev)
-        dw, db = grads[:n_out * n_in], grads[n_out * n_in:]
-        ptr = lambda t: C.c_void_p(t.data_ptr())
+        dw, db = grads[:n_out * n_in], (grads[n_out * n_in:] if ctx.has_bias else None)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         if ctx.lib.ctf_policy_linear_wgrad(ptr(dy), ptr(x), dy.shape[0], n_out, n_in, ptr(dw), ptr(db), dev.index,
                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) != 0:
             raise _abi.CtfLibraryError("ctf_policy_linear_wgrad: " + (ctx.lib.ctf_policy_last_error() or b"").decode())
@@ -252,6 +252,8 @@ class CtfPolicyNative(CtfPolicy):
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
     fused_head = False      # the network's tail fused behind the patch product (ctf_policy_fc1_patch_head): bit-identical, and measured
                             # no faster — 0.262 ms per call against 0.179 + 0.076 (the tail then runs at one block per CU) — so off
+    native_fc1_wgrad = False  # fc1's weight gradient by ctf_policy_linear_wgrad too: correct (tested) but no faster than the library's GEMM
+                              # (1.08 + 0.10 ms against 1.06 per 262 144 samples: one wave per SIMD, 17 M float atomics, dy re-read per slab)
     native_tail_wgrad = True  # fc2's and the heads' weight / bias gradients by ctf_policy_linear_wgrad (False: the library's GEMMs + reductions)
     fused_backward = True   # ... conv2's weight gradient inside the data-gradient pass (ctf_policy_front_backward; False: three launches)
     factored_fc1 = os.environ.get("CTF_POLICY_FACT", "1") != "0"  # act_from_codes(shared_view=True): fc1 as one GEMM row per (env, view) + a per-agent patch product
@@ -560,7 +562,10 @@ class CtfPolicyNative(CtfPolicy):
             # [256, Kp]: zero weight on the row's padding, and the bias in the column where the front writes 1.0 — the bias gradient then
             # falls out of the weight-gradient GEMM instead of a reduction over the batch of its own
             w = self.fc1.weight.index_select(1, p["col_src"]) * p["col_keep"] + self.fc1.bias[:, None] * p["one_col"]
-            x = torch.tanh(torch.nn.functional.linear(act, w))
+            if self.native_fc1_wgrad and w.shape[0] == 256 and w.shape[1] % 64 == 0:
+                x = torch.tanh(_TailLinear.apply(act, w, None, p["lib"]))  # fc1's weight gradient by the same kernel (column slabs)
+            else:
+                x = torch.tanh(torch.nn.functional.linear(act, w))
             if self.native_tail_wgrad and self.fc2.weight.shape == (128, 256) and self.n_actions < 16:
                 # fc2 and the two heads (as ONE 16-output layer) with native weight / bias gradients (_TailLinear)
                 x = torch.tanh(_TailLinear.apply(x, self.fc2.weight, self.fc2.bias, p["lib"]))

@@ -532,7 +532,8 @@ def test_backward_kernels_of_the_conv_front_match_their_float64_definitions(g, c
     assert torch.allclose(dw_f[4608:].double().reshape(16, 16, 9)[:, :c], dw1_want, rtol=1e-4, atol=1e-4 * float(dw1_want.abs().max()))
 
 
-@pytest.mark.parametrize("n_out,n_in,m", [(128, 256, 5000), (16, 128, 777), (128, 256, 64), (16, 128, 131072)])
+@pytest.mark.parametrize("n_out,n_in,m", [(128, 256, 5000), (16, 128, 777), (128, 256, 64), (16, 128, 131072), (256, 4160, 3000), (256, 2112, 129),
+                                          (256, 256, 70000)])
 def test_small_layer_weight_and_bias_gradients_match_float64(n_out, n_in, m):
     """ctf_policy_linear_wgrad: dw = dy^T x and db = sum(dy) over the samples, bf16 operands, float32 accumulation (atomics across
     blocks), against the float64 sums of the same bf16 values; added to what the buffers held."""
@@ -546,9 +547,11 @@ def test_small_layer_weight_and_bias_gradients_match_float64(n_out, n_in, m):
     dw = torch.full((n_out, n_in), 0.5, dtype=torch.float32, device="cuda")
     db = torch.full((n_out,), -2.0, dtype=torch.float32, device="cuda")
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    assert lib.ctf_policy_linear_wgrad(ptr(dy), ptr(x), m, n_out, n_in, ptr(dw), ptr(db), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    # (the fc1 form, 256 outputs, carries its bias in a weight column: no separate bias gradient)
+    assert lib.ctf_policy_linear_wgrad(ptr(dy), ptr(x), m, n_out, n_in, ptr(dw), ptr(db) if n_out != 256 else None, 0,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     want_w = dy.double().T @ x.double() + 0.5
-    want_b = dy.double().sum(0) - 2.0
+    want_b = dy.double().sum(0) - 2.0 if n_out != 256 else db.double()
     scale = float(want_w.abs().max())
     assert float((dw.double() - want_w).abs().max()) < 1e-5 * max(scale, 1.0) * (1 + m / 65536)
     assert float((db.double() - want_b).abs().max()) < 1e-5 * max(float(want_b.abs().max()), 1.0) * (1 + m / 65536)
