@@ -124,8 +124,8 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
             "losses_v_pg_entropy": [float(x) for x in losses],
             "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
             "note": "the learner is the reference's PPO update (ppo.py:174-242) on the compact rollout: the native conv front as the forward "
-                    "(ctf_policy_features_train), native data- and weight-gradient kernels (ctf_policy_front_dgrad / _wgrad), hipBLASLt GEMMs "
-                    "for the dense layers (policy_native._NativeFront)" +
+                    "(ctf_policy_features_train), its whole backward native (ctf_policy_front_backward), the small dense layers' weight / bias "
+                    "gradients native (ctf_policy_linear_wgrad), hipBLASLt GEMMs for fc1 and the dense layers' forward / data gradients" +
                     ("; data-parallel over the global minibatches, one flat gradient all-reduce per optimiser step" if lrn.dp else ""),
         })
     else:
