@@ -191,6 +191,19 @@ int ctf_policy_fc1_patch_head(const uint16_t* prow_dev, const int32_t* row_of_sl
                               int32_t n_actions, uint64_t seed, uint64_t offset, int32_t* action_dev, float* logprob_dev,
                               float* entropy_dev, float* value_dev, float* logits_dev, int32_t device_id, void* stream);
 
+/* The rollout collector's per-step bookkeeping as one launch — what PPOTrainer.get_single_rollout stores per trained agent and the joint
+ * action it hands to env.step (ppo.py:74-93): for trained slot k (agent trained_sel[k]) and env e, row k * n_envs + e of the outputs gets
+ * the agent's code bytes and metadata (binary16 -> float32), its action (int32 -> float32), log-prob and value; env_actions_out[e][n] gets
+ * agent n's action — from act_trained_dev / act_other_dev, rows slot * n_envs + e — mapped through reversed_action_lut[9] where bit n of
+ * team1_mask is set (REVERSED_ACTION_MAP, gridworld_ctf.py:147-196; the stored action is the un-mapped one, ppo.py:77).  trained_sel /
+ * other_sel / reversed_action_lut are HOST arrays; every agent is in exactly one of the two lists. */
+int ctf_rollout_store_step(const uint8_t* codes_dev, const uint16_t* meta_dev, int32_t n_envs, int32_t n_agents, int32_t cells,
+                           int32_t meta_len, const int32_t* trained_sel, int32_t n_trained, const int32_t* other_sel, int32_t n_other,
+                           const int32_t* act_trained_dev, const float* logprob_dev, const float* value_dev, const int32_t* act_other_dev,
+                           const uint8_t* reversed_action_lut, uint32_t team1_mask, uint8_t* grid_codes_out, float* metadata_out,
+                           float* actions_out, float* logprobs_out, float* values_out, int8_t* env_actions_out, int32_t device_id,
+                           void* stream);
+
 const char* ctf_policy_last_error(void);
 
 #ifdef __cplusplus

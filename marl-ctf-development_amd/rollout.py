@@ -18,11 +18,15 @@ The policy networks are the caller's (stock PyTorch modules with the reference's
 ``get_action_and_value(grid, metadata, use_action_mask)`` signature, agent_network.py:63-81); GAE and the PPO update
 stay the reference's code — they can consume the returned tensors as they are.
 """
+import ctypes as C
+
 import numpy as np
 
 try:
+    from . import _abi
     from .gridworld_ctf import _REVERSED_ACTIONS
 except ImportError:  # pragma: no cover
+    import _abi
     from gridworld_ctf import _REVERSED_ACTIONS
 
 
@@ -74,6 +78,10 @@ class BatchedRolloutCollector:
         # tolerate co-resident waves (profiles/r03_policy_roofline.md)
         self.overlap_teams = False
         self._side_stream = None
+        # compact mode: the per-step bookkeeping (ppo.py:74-93 — what is stored per trained agent, the joint action with team-1 agents'
+        # actions mapped back) as ONE launch (ctf_rollout_store_step) instead of ~17 small tensor kernels (0.15 of a 2.1 ms step)
+        self.native_store = True
+        self._store_args = None
 
     def use_codes(self, agent, opponent):
         if self.compact is None:
@@ -166,6 +174,38 @@ class BatchedRolloutCollector:
         mapped = self.rev_lut[env_act.long()]
         return trained, torch.where(self.is_team1[None, :], mapped, env_act).contiguous()
 
+    def _step_native(self, agent, opponent, t):
+        """One decision of every agent from the compact observation and its bookkeeping in one launch: rows t * A .. of the rollout
+        buffers and the env's joint action (``self._env_actions``)."""
+        torch, vec, A = self.torch, self.vec, self.A
+        E, N = vec.n_envs, vec.N_AGENTS
+        codes, meta = vec.observe_codes()  # default reversal: team(i) == 1
+        one_team = lambda agents: len({vec.AGENT_TEAMS[i] for i in agents}) == 1
+        if self._store_args is None:
+            lib = _abi.load_library()
+            mask_of = lambda idx: self.mask_flag.index_select(0, idx)[:, None].expand(-1, E).reshape(-1).contiguous()
+            team1 = sum(1 << i for i in range(N) if vec.AGENT_TEAMS[i] == 1)
+            self._store_args = dict(lib=lib, trained=(C.c_int32 * A)(*self.trained), others=(C.c_int32 * len(self.others))(*self.others),
+                                    lut=(C.c_uint8 * 9)(*[int(x) for x in self.rev_lut.tolist()]), team1=team1,
+                                    mask_t=mask_of(self.trained_idx), mask_o=mask_of(self.others_idx),
+                                    shared_t=one_team(self.trained), shared_o=one_team(self.others))
+        sa = self._store_args
+        a_act, a_lp, _, a_val = agent.act_from_codes(codes, meta, self.trained, sa["mask_t"], shared_view=sa["shared_t"], self_cells=vec.self_cells)
+        o_act = opponent.act_from_codes(codes, meta, self.others, sa["mask_o"], shared_view=sa["shared_o"], self_cells=vec.self_cells)[0]
+        i32 = lambda x: x.reshape(-1).to(torch.int32).contiguous()
+        f32 = lambda x: x.reshape(-1).to(torch.float32).contiguous()
+        a_act, o_act, a_lp, a_val = i32(a_act), i32(o_act), f32(a_lp), f32(a_val)
+        sl = slice(t * A, (t + 1) * A)
+        ptr = lambda x: C.c_void_p(x.data_ptr())
+        g = vec.GRID_SIZE
+        rc = sa["lib"].ctf_rollout_store_step(
+            ptr(codes), ptr(meta), E, N, g * g, vec.META_LEN, sa["trained"], A, sa["others"], len(self.others), ptr(a_act), ptr(a_lp), ptr(a_val),
+            ptr(o_act), sa["lut"], sa["team1"], ptr(self.grid_codes[sl]), ptr(self.metadata_states[sl]), ptr(self.actions[sl]),
+            ptr(self.logprobs[sl]), ptr(self.values[sl]), ptr(self._env_actions), vec.device.index,
+            C.c_void_p(torch.cuda.current_stream(vec.device).cuda_stream))
+        if rc != 0:
+            raise _abi.CtfLibraryError("ctf_rollout_store_step: " + (sa["lib"].ctf_policy_last_error() or b"").decode())
+
     def collect(self, agent, opponent, reset=True, handoff=None, handoff_chunk=16):
         """-> dict with the tensors ``get_single_rollout`` returns, each with an env axis after the slot axis.  In compact
         mode ``grid_codes`` / ``next_grid_codes`` stand in for ``grid_states`` / ``next_grid_state``.
@@ -193,8 +233,19 @@ class BatchedRolloutCollector:
             vec.reset()  # ppo.py:57
         self.dones.zero_()
         done = None
+        fast = bool(use_codes and self.native_store and vec.device.type == "cuda" and not self.overlap_teams)
+        if fast:  # the masking decision of a trained slot is a constant of the collector: written once, not per step
+            self.use_action_mask.view(self.T, A, E)[:] = self.mask_flag.index_select(0, self.trained_idx)[None, :, None]
         with torch.no_grad():
             for t in range(self.T):
+                if fast:
+                    self._step_native(agent, opponent, t)
+                    rewards, done = vec.step(self._env_actions)
+                    self.rewards[t * A:(t + 1) * A] = rewards.index_select(1, self.trained_idx).transpose(0, 1)
+                    if handoff is not None and ((t + 1) % handoff_chunk == 0 or t + 1 == self.T):
+                        handoff.launch(sent, (t + 1) * A, local)
+                        sent = (t + 1) * A
+                    continue
                 (a_act, a_lp, a_val, a_grid, a_md, a_mask), env_act = self.joint_actions(agent, opponent, use_codes)
                 sl = slice(t * A, (t + 1) * A)
                 if use_codes:
