@@ -169,6 +169,14 @@ int ctf_policy_features_fact(const uint8_t* codes_dev, const uint16_t* meta_dev,
                              const float* conv2_bias_dev, const int32_t* slot_of_dev, uint16_t* view_dev, uint16_t* prow_dev,
                              int32_t device_id, void* stream);
 
+/* yview = view x W_flat^T as a stream over the view matrix (a block: 128 rows x all 256 outputs, W resident in L2): what the library's
+ * GEMM computes for the factored path (torch.mm(view, W_flat^T, out_dtype=float32)), same operands, float32 accumulation in k order.
+ *   view_dev     bf16 [n_rows][kv] from ctf_policy_features_fact (kv = ctf_policy_fact_view_stride(): 2048 or 4096; a multiple of 64 is required)
+ *   w_rows_dev   bf16 [256][kv]: fc1.weight's conv columns * 2 log2(e) in the view's column order (zero on the row's padding)
+ *   yview_dev    float [n_rows][256] out */
+int ctf_policy_view_gemm(const uint16_t* view_dev, const uint16_t* w_rows_dev, int32_t n_rows, int32_t kv, float* yview_dev,
+                         int32_t device_id, void* stream);
+
 /*   yview_dev        float [n_envs][256]: view x W_flat^T with W_flat = fc1.weight's conv columns * 2 log2(e) in the view's column order
  *   patch_frag_dev   bf16 [(G-4)^2 + 2][2][8][64][8]: MFMA 32x32x16 A-operand fragments of fc1.weight * 2 log2(e):
  *                    [p][s][t][lane][j] = W[out = 32 t + (lane & 31)][column of channel 16 s + 8 (lane >> 5) + j at position p];

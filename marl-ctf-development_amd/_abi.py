@@ -154,6 +154,7 @@ SYMBOLS = {
     "ctf_policy_fact_bucket": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, C.c_int32, _P]),
     "ctf_policy_features_fact": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
                                            _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "ctf_policy_view_gemm": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "ctf_policy_fc1_patch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "ctf_policy_fc1_patch_head": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32,
                                             C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, C.c_int32, _P]),

@@ -930,3 +930,130 @@ extern "C" int ctf_policy_fc1_patch_head(const uint16_t* prow_dev, const int32_t
     if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// the view GEMM: yview[E][256] = view[E][KV] x W_flat^T, float32 out
+// ------------------------------------------------------------------------------------------------
+// OFF by default (policy_native.py: native_view_gemm): measured 0.205 - 0.21 ms a call against the library's 0.185 (both 0.175 under
+// rocprofv3; results bit-identical), in every form tried — register staging at 4 and 8 waves, this LDS-DMA ring, a staggered walk over K,
+// a tile-blocked view layout (profiles/r04_view_gemm.md).  The shape (M = 65 536, N = 256, K = 4 096: 137 GFLOP against 0.54 GB) is bound
+// by what one CU's vector-memory path takes in: 2.1 MB of view rows from HBM (~24 GB/s a CU at the chip's ~6 TB/s) plus, for a 128-row
+// tile, 4.2 MB of W from L2 (~70 GB/s a CU) — 0.15 ms, and the MFMAs (37 % busy) hide under it.  Kept as the tested statement of that.
+//
+// A block of 8 waves takes 128 rows and ALL 256 columns (W, 2 MB, stays in L2), K in chunks of 64; a chunk of both operands (16 + 32 KB)
+// goes global -> LDS directly (global_load_lds_dwordx4: no registers, no ds_write) into a ring of THREE stages, two chunks ahead of its
+// use, with one raw barrier a chunk and counted waits:
+//     chunk c:   s_waitcnt vmcnt(6)   this wave's 6 pieces of chunk c have landed (the 6 of chunk c + 1 may still fly)
+//                s_barrier            everybody's have, and everybody has finished reading chunk c - 1
+//                6 x glds             chunk c + 2 -> the stage chunk c - 1 was read from
+//                16 ds_read_b128 + 16 MFMA on chunk c
+// An LDS-DMA instruction writes 1 KiB contiguously (lane L -> bytes 16 L ..), so the stage is unpadded [384 rows][128 B] and the bank
+// spread comes from the SOURCE side: slot s of row r holds the row's 16-byte piece s ^ ((r >> 1) & 7); a ds_read_b128 lane group (16
+// rows, one piece) then covers the 16 slots of a 256-byte bank row exactly once.  Wave w owns rows 64 (w >> 2) .. + 63 x outputs
+// 64 (w & 3) .. + 63 (32x32x16 MFMA, weights as the A operand: a lane ends with 4 consecutive outputs of ONE row).
+struct ViewGemmArgs {
+    const uint16_t* a;    // bf16 [M][K]
+    const uint16_t* w;    // bf16 [256][K]
+    float* out;           // f32 [M][256]
+    int32_t M, K;
+};
+#define VG_STAGE 49152   // bytes of a stage: 128 view rows then 256 weight rows of 64 k
+__device__ __forceinline__ void vg_glds16(const uint8_t* gsrc, uint32_t lds_dst) {
+    // (hand-placed: the compiler neither sees the load nor waits for it — the loop's own s_waitcnt vmcnt(6) does; M0 is put back)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_view_gemm(ViewGemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t vg_lds[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int n32 = lane & 31, hh = lane >> 5;
+    const int row0 = blockIdx.x * 128;
+    const int n_chunks = g.K >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)vg_lds;
+    // piece i of this wave = staged rows 8 (6 wave + i) .. + 7: lane -> row + (lane >> 3), slot lane & 7
+    const uint8_t* src[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int r = 8 * (6 * wave + i) + (lane >> 3);
+        const int pc = (lane & 7) ^ ((r >> 1) & 7);
+        src[i] = r < 128 ? (const uint8_t*)g.a + (size_t)min(row0 + r, g.M - 1) * g.K * 2 + pc * 16
+                         : (const uint8_t*)g.w + (size_t)(r - 128) * g.K * 2 + pc * 16;
+    }
+    const uint32_t dst0 = lds0 + 6 * wave * 1024;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][m][r] = 0.0f;
+    const int mh = wave >> 2, nq = wave & 3;
+    // fragment reads: rows 64 mh + 32 m + n32 (view) / 128 + 64 nq + 32 i + n32 (weights), piece 2 u + hh -> slot (2 u + hh) ^ ((n32 >> 1) & 7)
+    const int sw = (n32 >> 1) & 7;
+    const uint8_t* const arow = vg_lds + (64 * mh + n32) * 128;
+    const uint8_t* const wrow = vg_lds + (128 + 64 * nq + n32) * 128;
+    int slot[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) slot[u] = ((2 * u + hh) ^ sw) * 16;
+#define VG_ISSUE(C, ST)  _Pragma("unroll") for (int i = 0; i < 6; i++) vg_glds16(src[i] + (size_t)(C) * 128, dst0 + (ST) * VG_STAGE + i * 1024)
+    VG_ISSUE(0, 0);
+    VG_ISSUE(min(1, n_chunks - 1), 1);
+    int st = 0, st2 = 2;   // stage of chunk c / of chunk c + 2
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; c++) {
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        VG_ISSUE(min(c + 2, n_chunks - 1), st2);   // (past the end: the last chunk once more, into a stage nobody reads any longer)
+        const uint8_t* A = arow + st * VG_STAGE;
+        const uint8_t* B = wrow + st * VG_STAGE;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            u32x4_t wf[2], af[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) wf[i] = *(const u32x4_t*)(B + i * 4096 + slot[u]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) af[m] = *(const u32x4_t*)(A + m * 4096 + slot[u]);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+                    acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf[i]), as_bf16x8(af[m]), acc[i][m], 0, 0, 0);
+        }
+        st = st == 2 ? 0 : st + 1;
+        st2 = st2 == 2 ? 0 : st2 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two refetches past the end: landed before the wave may go
+#undef VG_ISSUE
+    // D[n][row]: a lane holds column `row` (64 mh + 32 m + n32) and, per register group q, outputs n0 = 64 nq + 32 i + 8 q + 4 hh .. + 3
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int row = row0 + 64 * mh + 32 * m + n32;
+        if (row < g.M) {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n0 = 64 * nq + 32 * i + 8 * q + 4 * hh;
+                    *(f32x4_t*)(g.out + (size_t)row * 256 + n0) = (f32x4_t){acc[i][m][4 * q], acc[i][m][4 * q + 1], acc[i][m][4 * q + 2], acc[i][m][4 * q + 3]};
+                }
+        }
+    }
+}
+
+extern "C" int ctf_policy_view_gemm(const uint16_t* view_dev, const uint16_t* w_rows_dev, int32_t n_rows, int32_t kv, float* yview_dev,
+                                    int32_t device_id, void* stream) {
+    if (!view_dev || !w_rows_dev || !yview_dev) return ctf_policy_fail("null argument");
+    if (n_rows < 1 || kv < 64 || (kv & 63)) return ctf_policy_fail("n_rows >= 1 and kv a multiple of 64");
+    if (((uintptr_t)view_dev | (uintptr_t)w_rows_dev | (uintptr_t)yview_dev) & 15) return ctf_policy_fail("16-byte alignment");
+    ViewGemmArgs g;
+    g.a = view_dev; g.w = w_rows_dev; g.out = yview_dev; g.M = n_rows; g.K = kv;
+    DeviceScope scope(device_id);
+    if (!scope.ok) return ctf_policy_fail("hipSetDevice failed");
+    const int sh = 3 * VG_STAGE;
+    hipError_t err = hipFuncSetAttribute((const void*)k_view_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+    if (err == hipSuccess) hipLaunchKernelGGL(k_view_gemm, dim3((n_rows + 127) / 128), dim3(512), sh, (hipStream_t)stream, g);
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
+    return 0;
+}

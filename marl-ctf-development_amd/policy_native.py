@@ -252,6 +252,8 @@ class CtfPolicyNative(CtfPolicy):
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
     fused_head = False      # the network's tail fused behind the patch product (ctf_policy_fc1_patch_head): bit-identical, and measured
                             # no faster — 0.262 ms per call against 0.179 + 0.076 (the tail then runs at one block per CU) — so off
+    native_view_gemm = False  # the factored path's view GEMM by ctf_policy_view_gemm: bit-identical to torch.mm -> hipBLASLt (tested) and
+                              # measured slower, 0.205 against 0.185 ms a call: both wait for the same bytes (profiles/r04_view_gemm.md)
     native_fc1_wgrad = False  # fc1's weight gradient by ctf_policy_linear_wgrad too: correct (tested) but no faster than the library's GEMM
                               # (1.08 + 0.10 ms against 1.06 per 262 144 samples: one wave per SIMD, 17 M float atomics, dy re-read per slab)
     native_tail_wgrad = True  # fc2's and the heads' weight / bias gradients by ctf_policy_linear_wgrad (False: the library's GEMMs + reductions)
@@ -366,7 +368,8 @@ class CtfPolicyNative(CtfPolicy):
             )
             if "pf" in m:  # the factored fc1 path (ctf_policy_fc1_patch): W_flat in the view's column order, the per-position fragments, the bias
                 kv = lib.ctf_policy_fact_view_stride(self.grid_size)
-                self._prep.update(fc1_view_wt=self._prep["fc1_w"][:, :kv].t().contiguous(),  # [KV, 256]: the GEMM's right operand as it is
+                self._prep.update(fc1_view_wt=self._prep["fc1_w"][:, :kv].t().contiguous(),  # [KV, 256]: the library GEMM's right operand as it is
+                                  fc1_view_w=self._prep["fc1_w"][:, :kv].contiguous(),  # [256, KV]: ctf_policy_view_gemm's
                                   pf=take(self.fc1.weight.detach().reshape(-1).double(), m["pf"], _TWO_LOG2E, bf),
                                   fc1_b32=(self.fc1.bias.detach().double() * _TWO_LOG2E).to(f32).contiguous())
         return self
@@ -476,7 +479,10 @@ class CtfPolicyNative(CtfPolicy):
         def front_and_gemm(view):
             ok(lib.ctf_policy_features_fact(ptr(codes), ptr(meta), ptr(self_cells), E, N, G, M, sel_arr, A, ptr(p["f1"]), ptr(p["b1"]), ptr(p["f2"]),
                                             ptr(p["b2"]), ptr(b["slot_of"]), ptr(view), ptr(b["prow"]), dev.index, stream), "ctf_policy_features_fact")
-            torch.mm(view, p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"])  # float32 out: the patch product is added before the one rounding
+            if self.native_view_gemm:  # float32 out either way: the patch product is added before the one rounding
+                ok(lib.ctf_policy_view_gemm(ptr(view), ptr(p["fc1_view_w"]), E, b["kv"], ptr(b["yview"]), dev.index, stream), "ctf_policy_view_gemm")
+            else:
+                torch.mm(view, p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"])
 
         if not b.get("placed"):
             # Large allocations on this pool come in two kinds: the slow one costs the front's stores and the GEMM's reads

@@ -234,3 +234,25 @@ def test_the_fused_tail_gives_the_separate_calls_results_bit_for_bit():
         for a, b, name in zip(got, want, ("action", "logprob", "entropy", "value", "logits")):
             assert torch.equal(a, b), name
     assert bool((got[0][mask == 1] < 5).all())
+
+
+@pytest.mark.parametrize("rows,kv", [(1, 2048), (127, 2048), (128, 4096), (1000, 4096), (4099, 2048)])
+def test_view_gemm_equals_the_float64_product_of_its_bf16_operands(rows, kv):
+    """ctf_policy_view_gemm (float32 accumulation in k order) against float64 on the same operands, ragged last tile included;
+    the library product it replaces is held to the same bound."""
+    import ctypes as C
+    lib = importlib.import_module("marl-ctf-development_amd._abi").load_library()
+    gen = torch.Generator(device="cuda").manual_seed(rows + kv)
+    a = (torch.rand((rows, kv), device="cuda", generator=gen) * 2 - 1).to(torch.bfloat16)
+    w = (torch.randn((256, kv), device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    out = torch.full((rows + 1, 256), 7.0, device="cuda")  # a guard row: nothing may be written past the last row
+    rc = lib.ctf_policy_view_gemm(C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()), rows, kv, C.c_void_p(out.data_ptr()), 0,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.ctf_policy_last_error()
+    want = a.double() @ w.double().T
+    # |sum| of kv products of magnitude <= ~2: float32 accumulation error << 1e-3
+    assert float((out[:rows].double() - want).abs().max()) < 2e-3
+    assert float((out[rows] - 7.0).abs().max()) == 0.0
+    libm = torch.mm(a, w.t().contiguous(), out_dtype=torch.float32)
+    assert float((libm.double() - want).abs().max()) < 2e-3
+    assert lib.ctf_policy_view_gemm(C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()), rows, 100, C.c_void_p(out.data_ptr()), 0, None) != 0

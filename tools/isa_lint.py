@@ -24,7 +24,7 @@ from collections import defaultdict
 LABEL = re.compile(r"^(\.LBB\d+_\d+):")
 FUNC = re.compile(r"^([A-Za-z_][\w$.]*):\s*(;.*)?$")
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-LOAD = re.compile(r"^\s*(global|buffer|flat)_load_(\w+)\s+(v\d+|v\[\d+:\d+\])")
+LOAD = re.compile(r"^\s*(global|buffer|flat)_load_(?!lds_)(\w+)\s+(v\d+|v\[\d+:\d+\])")  # (an LDS-DMA load has no register destination)
 WIDTH = {"dwordx2": 2, "dwordx3": 3, "dwordx4": 4}
 
 

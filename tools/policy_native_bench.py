@@ -77,11 +77,15 @@ def main():
                                                                             ptr(p["f2"]), ptr(p["b2"]), ptr(b["slot_of"]), ptr(b["view"]), ptr(b["prow"]), 0, st())
                                               for t in (0, 1)])
         out["fact_view_gemm_x2"] = timed(lambda: [torch.mm(b["view"], p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"]) for t in (0, 1)])
+        out["fact_view_gemm_native_x2"] = timed(lambda: [lib.ctf_policy_view_gemm(ptr(b["view"]), ptr(p["fc1_view_w"]), E, b["kv"], ptr(b["yview"]), 0, st()) for t in (0, 1)])
         out["fact_patch_x2"] = timed(lambda: [lib.ctf_policy_fc1_patch(ptr(b["prow"]), ptr(b["row_of_slot"]), ptr(b["work"]), ptr(b["yview"]), ptr(p["pf"]),
                                                                         ptr(p["fc1_b32"]), E, A, G, M, ptr(b["y1"]), 0, st()) for t in (0, 1)])
         out["fact_fc1_from_codes_x2"] = timed(lambda: [net.fc1_from_codes_factored(codes, meta, teams[t], sc) for t in (0, 1)])
         masks = [torch.ones(A * E, device="cuda") for _ in (0, 1)]
         out["act_two_teams_factored"] = timed(lambda: [net.act_from_codes(codes, meta, teams[t], masks[t], shared_view=True, self_cells=sc) for t in (0, 1)])
+        net.native_view_gemm = False
+        out["act_two_teams_factored_library_gemm"] = timed(lambda: [net.act_from_codes(codes, meta, teams[t], masks[t], shared_view=True, self_cells=sc) for t in (0, 1)])
+        net.native_view_gemm = True
         net.factored_fc1 = False
         out["act_two_teams_unfactored"] = timed(lambda: [net.act_from_codes(codes, meta, teams[t], masks[t], shared_view=True, self_cells=sc) for t in (0, 1)])
         net.factored_fc1 = True
