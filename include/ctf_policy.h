@@ -199,6 +199,14 @@ int ctf_policy_fc1_patch_head(const uint16_t* prow_dev, const int32_t* row_of_sl
                               int32_t n_actions, uint64_t seed, uint64_t offset, int32_t* action_dev, float* logprob_dev,
                               float* entropy_dev, float* value_dev, float* logits_dev, int32_t device_id, void* stream);
 
+/* fc1's data gradient in the learner's backward (ppo.py:231-233 -> autograd through agent_network.py:16): d_act = dy x W, what
+ * torch.mm(dy, W) computes (float32 accumulation, one rounding to bf16), as an HBM-write-bound stream.
+ *   dy_dev     bf16 [n_samples][256]: the gradient at fc1's output; n_samples a multiple of 32
+ *   wt_dev     bf16 [kp][256]: W^T, W = the [256][kp] matrix fc1's forward multiplied by (kp a multiple of 64)
+ *   d_act_dev  bf16 [n_samples][kp] out */
+int ctf_policy_fc1_dgrad(const uint16_t* dy_dev, const uint16_t* wt_dev, int32_t n_samples, int32_t kp, uint16_t* d_act_dev,
+                         int32_t device_id, void* stream);
+
 /* The rollout collector's per-step bookkeeping as one launch — what PPOTrainer.get_single_rollout stores per trained agent and the joint
  * action it hands to env.step (ppo.py:74-93): for trained slot k (agent trained_sel[k]) and env e, row k * n_envs + e of the outputs gets
  * the agent's code bytes and metadata (binary16 -> float32), its action (int32 -> float32), log-prob and value; env_actions_out[e][n] gets

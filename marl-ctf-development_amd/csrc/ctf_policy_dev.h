@@ -15,6 +15,19 @@
 //   bit5 team kernel: half of the shared activation stores skipped, bit6 team kernel: rows env-major
 #ifndef POL_ABLATE
 #define POL_ABLATE 0
+// host side: make device_id current for the duration of an entry point, then put the caller's device back
+struct DeviceScope {
+    int prev = -1, want;
+    bool ok = true;
+    explicit DeviceScope(int device_id) : want(device_id) {
+        if (hipGetDevice(&prev) != hipSuccess) ok = false;
+        else if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
+    }
+    ~DeviceScope() {
+        if (ok && prev != want) (void)hipSetDevice(prev);
+    }
+};
+
 #endif
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

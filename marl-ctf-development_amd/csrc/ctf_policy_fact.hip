@@ -745,18 +745,6 @@ extern "C" int32_t ctf_policy_fact_max_tiles(int32_t n_envs, int32_t n_sel, int3
     return (int32_t)(((int64_t)n_envs * n_sel + FACT_MT - 1) / FACT_MT + grid_size * grid_size);
 }
 
-struct DeviceScope {
-    int prev = -1, want;
-    bool ok = true;
-    explicit DeviceScope(int device_id) : want(device_id) {
-        if (hipGetDevice(&prev) != hipSuccess) ok = false;
-        else if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
-    }
-    ~DeviceScope() {
-        if (ok && prev != want) (void)hipSetDevice(prev);
-    }
-};
-
 static int pack_sel(const int32_t* agent_sel, int n_sel, int n_agents, uint64_t* out) {
     if (!agent_sel || n_sel < 1 || n_sel > 4) return ctf_policy_fail("the factored path takes 1..4 selected agents");
     uint64_t p = 0;

@@ -283,3 +283,136 @@ extern "C" int ctf_rollout_store_step(const uint8_t* codes_dev, const uint16_t* 
     if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// fc1's data gradient: d_act[M][Kp] = dy[M][256] x W[256][Kp]   (ppo.py:231-233 -> autograd through agent_network.py:16)
+// ------------------------------------------------------------------------------------------------
+// 2.18 GB of bf16 written per 262 144 samples against 0.56 TFLOP: HBM-write bound; the library's GEMM takes 1.06-1.08 ms
+// (profiles/r04_learner_roofline.md), this kernel 0.76 (same bits).  The short contraction (256) lets a wave keep ITS 32 rows of dy in
+// registers for the whole kernel (16 B-operand fragments); a block of 8 waves = 256 rows walks over the Kp columns in chunks of 64:
+// the chunk of W^T ([64 columns][256 k], 32 KB, L2-resident) comes global -> LDS by DMA into a ring of three stages, two chunks ahead —
+//     chunk c:   s_waitcnt vmcnt(12)  this wave's 4 pieces of chunk c have landed (younger: 4 stores, the 4 pieces of c + 1, 4 stores)
+//                s_barrier            everybody's have, and everybody has finished reading chunk c - 1
+//                4 x glds             chunk c + 2 -> the stage chunk c - 1 was read from
+//                32 ds_read_b128 + 32 MFMA (32x32x16; W^T rows as the A operand: D[column][row])
+//                the wave's [32 rows][64 columns] through its own LDS patch -> four stores of whole 128-byte lines per row
+// (loads, stores and LDS-DMA are counted together per wave, in issue order, which is what makes the 12 exact).  An LDS-DMA piece is
+// 1 KiB = two W^T rows of 512 B; slot s of row r holds the row's 16-byte piece s ^ (r & 15), so that the 16 rows of a ds_read_b128
+// lane group fall on the 16 slots of a 256-byte bank row.
+// Measured around it (profiles/r04_fc1_dgrad.md): the stores alone 0.59 ms (3.7 TB/s: 128-byte pieces at a row stride of 8 320 B), the
+// arithmetic alone 0.54; fragments prefetched four k-steps ahead, tiles mapped XCD-contiguously, the next chunk's DMA ahead of the
+// stores, and two loader waves of their own (compute waves that never wait for vector memory) all landed within 0.76-0.82.
+struct Fc1DgradArgs {
+    const uint16_t* dy;   // bf16 [M][256]
+    const uint16_t* wt;   // bf16 [Kp][256]: W^T
+    uint16_t* out;        // bf16 [M][Kp]
+    int32_t M, Kp;
+};
+#define FD_STAGE 32768
+#define FD_OROW 144      // bytes of a row of the wave's output patch: 64 columns + 16 of padding
+__device__ __forceinline__ void fd_glds16(const uint8_t* gsrc, uint32_t lds_dst) {
+    uint32_t keep;   // (hand-placed: the loop's own counted s_waitcnt covers it; M0 is put back)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_fc1_dgrad(Fc1DgradArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t fd_lds[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int n32 = lane & 31, hh = lane >> 5;
+    const int row0 = blockIdx.x * 256 + 32 * wave;       // this wave's rows
+    const int n_chunks = g.Kp >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)fd_lds;
+    uint8_t* const opatch = fd_lds + 3 * FD_STAGE + wave * 32 * FD_OROW;
+    // piece i of this wave = W^T rows 2 (4 wave + i), + 1 of the chunk: lane -> row + (lane >> 5), slot lane & 31
+    const uint8_t* src[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = 2 * (4 * wave + i) + (lane >> 5);
+        src[i] = (const uint8_t*)g.wt + (size_t)r * 512 + (((lane & 31) ^ (r & 15)) * 16);
+    }
+    const uint32_t dst0 = lds0 + 4 * wave * 1024;
+#define FD_ISSUE(C, ST)  _Pragma("unroll") for (int i = 0; i < 4; i++) fd_glds16(src[i] + (size_t)(C) * (64 * 512), dst0 + (ST) * FD_STAGE + i * 1024)
+    FD_ISSUE(0, 0);
+    FD_ISSUE(min(1, n_chunks - 1), 1);
+    // the wave's dy rows as B-operand fragments: lane -> row n32, k = 16 u + 8 hh ..
+    u32x4_t dyf[16];
+    {
+        const uint8_t* dyrow = (const uint8_t*)g.dy + (size_t)min(row0 + n32, g.M - 1) * 512 + hh * 16;
+#pragma unroll
+        for (int u = 0; u < 16; u++) dyf[u] = *(const u32x4_t*)(dyrow + u * 32);
+    }
+    // stores of the patch: pass t -> patch row (lane >> 3) + 8 t, 16-byte piece lane & 7
+    const int orow = lane >> 3, opc = lane & 7;
+    uint8_t* const gout = (uint8_t*)g.out + (size_t)(row0 + orow) * g.Kp * 2 + opc * 16;
+    const size_t gstep = (size_t)8 * g.Kp * 2;
+    const uint8_t* const wrow = fd_lds + n32 * 512;
+    const int sw = n32 & 15;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dy fragments; the two first chunks too — once)
+    const bool live = row0 < g.M;   // (M is a multiple of 32: a wave's rows exist or do not; a wave without rows still loads its pieces of W^T)
+    int st = 0, st2 = 2;
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; c++) {
+        if (live) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // (c = 0: nothing is in flight)
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // no stores in between
+        asm volatile("s_barrier" ::: "memory");
+        FD_ISSUE(min(c + 2, n_chunks - 1), st2);   // (past the end: the last chunk once more, into a stage nobody reads any longer)
+        const uint8_t* W = wrow + st * FD_STAGE;
+        f32x16_t acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const u32x4_t wf = *(const u32x4_t*)(W + i * (32 * 512) + (((2 * u + hh) ^ sw) * 16));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wf), as_bf16x8(dyf[u]), acc[i], 0, 0, 0);
+            }
+        }
+        // D[column 32 i + 8 q + 4 hh + r][row n32] -> the patch [row][64 columns]
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32x2_t v;
+                v[0] = pack_bf16(acc[i][4 * q], acc[i][4 * q + 1]);
+                v[1] = pack_bf16(acc[i][4 * q + 2], acc[i][4 * q + 3]);
+                *(u32x2_t*)(opatch + n32 * FD_OROW + (32 * i + 8 * q + 4 * hh) * 2) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        u32x4_t o[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) o[t] = *(const u32x4_t*)(opatch + (orow + 8 * t) * FD_OROW + opc * 16);
+        if (live) {   // exactly four store instructions a chunk: the counted wait above
+#pragma unroll
+            for (int t = 0; t < 4; t++) *(u32x4_t*)(gout + t * gstep + (size_t)c * 128) = o[t];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is read before the next chunk overwrites it
+        __builtin_amdgcn_wave_barrier();
+        st = st == 2 ? 0 : st + 1;
+        st2 = st2 == 2 ? 0 : st2 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two refetches past the end: landed before the wave may go
+#undef FD_ISSUE
+}
+
+extern "C" int ctf_policy_fc1_dgrad(const uint16_t* dy_dev, const uint16_t* wt_dev, int32_t n_samples, int32_t kp, uint16_t* d_act_dev,
+                                    int32_t device_id, void* stream) {
+    if (!dy_dev || !wt_dev || !d_act_dev) return ctf_policy_fail("null argument");
+    if (n_samples < 32 || (n_samples & 31)) return ctf_policy_fail("n_samples must be a positive multiple of 32");
+    if (kp < 64 || (kp & 63)) return ctf_policy_fail("kp must be a multiple of 64");
+    if (((uintptr_t)dy_dev | (uintptr_t)wt_dev | (uintptr_t)d_act_dev) & 15) return ctf_policy_fail("16-byte alignment");
+    Fc1DgradArgs g;
+    g.dy = dy_dev; g.wt = wt_dev; g.out = d_act_dev; g.M = n_samples; g.Kp = kp;
+    DeviceScope scope(device_id);
+    if (!scope.ok) return ctf_policy_fail("hipSetDevice failed");
+    const int sh = 3 * FD_STAGE + 8 * 32 * FD_OROW;
+    hipError_t err = hipFuncSetAttribute((const void*)k_fc1_dgrad, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+    if (err == hipSuccess) hipLaunchKernelGGL(k_fc1_dgrad, dim3((n_samples + 255) / 256), dim3(512), sh, (hipStream_t)stream, g);
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
+    return 0;
+}

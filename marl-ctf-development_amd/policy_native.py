@@ -247,6 +247,39 @@ class _TailLinear(torch.autograd.Function):
         return dx, dw.view(n_out, n_in), db, None
 
 
+class _Fc1Linear(torch.autograd.Function):
+    """y = act @ w^T for fc1 of a TRAINING step (w [256, Kp] carries the bias in the column where the front writes 1.0).  Forward and
+    weight gradient are the library's GEMMs; the data gradient d_act = dy @ w — 8.3 KB written per sample, which the library's kernel
+    does at a quarter of the HBM rate — is ctf_policy_fc1_dgrad."""
+
+    @staticmethod
+    def forward(ctx, act, w, lib):
+        wb = w.to(torch.bfloat16)
+        ctx.save_for_backward(act, wb)
+        ctx.lib = lib
+        return torch.nn.functional.linear(act, wb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        act, wb = ctx.saved_tensors
+        dy = dy.to(torch.bfloat16).contiguous()
+        dev = dy.device
+        dw = torch.mm(dy.t(), act).float() if ctx.needs_input_grad[1] else None  # (bf16 out, as autocast's linear backward has it)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            m, kp = int(dy.shape[0]), int(wb.shape[1])
+            if m % 32 == 0 and kp % 64 == 0:
+                dx = torch.empty((m, kp), dtype=torch.bfloat16, device=dev)
+                wt = wb.t().contiguous()
+                ptr = lambda t: C.c_void_p(t.data_ptr())
+                if ctx.lib.ctf_policy_fc1_dgrad(ptr(dy), ptr(wt), m, kp, ptr(dx), dev.index,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) != 0:
+                    raise _abi.CtfLibraryError("ctf_policy_fc1_dgrad: " + (ctx.lib.ctf_policy_last_error() or b"").decode())
+            else:
+                dx = torch.mm(dy, wb)
+        return dx, dw, None
+
+
 class CtfPolicyNative(CtfPolicy):
     native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
@@ -256,6 +289,7 @@ class CtfPolicyNative(CtfPolicy):
                               # measured slower, 0.205 against 0.185 ms a call: both wait for the same bytes (profiles/r04_view_gemm.md)
     native_fc1_wgrad = False  # fc1's weight gradient by ctf_policy_linear_wgrad too: correct (tested) but no faster than the library's GEMM
                               # (1.08 + 0.10 ms against 1.06 per 262 144 samples: one wave per SIMD, 17 M float atomics, dy re-read per slab)
+    native_fc1_dgrad = os.environ.get("CTF_FC1_DGRAD", "1") != "0"  # fc1's data gradient by ctf_policy_fc1_dgrad (off: the library's GEMM)
     native_tail_wgrad = True  # fc2's and the heads' weight / bias gradients by ctf_policy_linear_wgrad (False: the library's GEMMs + reductions)
     fused_backward = True   # ... conv2's weight gradient inside the data-gradient pass (ctf_policy_front_backward; False: three launches)
     factored_fc1 = os.environ.get("CTF_POLICY_FACT", "1") != "0"  # act_from_codes(shared_view=True): fc1 as one GEMM row per (env, view) + a per-agent patch product
@@ -570,6 +604,8 @@ class CtfPolicyNative(CtfPolicy):
             w = self.fc1.weight.index_select(1, p["col_src"]) * p["col_keep"] + self.fc1.bias[:, None] * p["one_col"]
             if self.native_fc1_wgrad and w.shape[0] == 256 and w.shape[1] % 64 == 0:
                 x = torch.tanh(_TailLinear.apply(act, w, None, p["lib"]))  # fc1's weight gradient by the same kernel (column slabs)
+            elif self.native_fc1_dgrad and w.shape[0] == 256 and w.shape[1] % 64 == 0:
+                x = torch.tanh(_Fc1Linear.apply(act, w, p["lib"]))
             else:
                 x = torch.tanh(torch.nn.functional.linear(act, w))
             if self.native_tail_wgrad and self.fc2.weight.shape == (128, 256) and self.n_actions < 16:

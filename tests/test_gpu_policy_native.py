@@ -580,3 +580,54 @@ def test_native_tail_gradients_equal_the_library_paths():
     for k in outs[0][2]:
         a, bgrad = outs[0][2][k].double(), outs[1][2][k].double()
         assert float((a - bgrad).abs().max()) <= 2e-2 * max(float(bgrad.abs().max()), 1e-6), (k, float((a - bgrad).abs().max()), float(bgrad.abs().max()))
+
+
+@pytest.mark.parametrize("m,kp", [(32, 64), (256, 4160), (3008, 2112), (8192 + 96, 4160)])
+def test_fc1_data_gradient_is_the_float64_product_rounded_once(m, kp):
+    """ctf_policy_fc1_dgrad: d_act = dy @ W (bf16 operands, float32 accumulation, ONE rounding to bf16) against float64 on the same
+    operands — within one bf16 spacing of the exact value everywhere; ragged last block (waves without rows), nothing written beyond."""
+    import ctypes as C
+
+    abi = importlib.import_module("marl-ctf-development_amd._abi")
+    lib = abi.load_library()
+    g = torch.Generator(device="cuda").manual_seed(m + kp)
+    dy = (torch.randn((m, 256), generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    w = (torch.randn((256, kp), generator=g, device="cuda") * 0.3).to(torch.bfloat16)
+    wt = w.t().contiguous()
+    out = torch.full((m + 1, kp), 3.0, dtype=torch.bfloat16, device="cuda")  # a guard row behind the matrix
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.ctf_policy_fc1_dgrad(ptr(dy), ptr(wt), m, kp, ptr(out), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0, \
+        lib.ctf_policy_last_error()
+    want = dy.double() @ w.double()
+    got = out[:m].double()
+    spacing = torch.pow(2.0, torch.floor(torch.log2(want.abs().clamp_min(1e-30))) - 7)
+    assert bool(((got - want).abs() <= spacing * 0.5 * (1 + 1e-6) + 1e-6).all()), float(((got - want).abs() / spacing).max())
+    assert float((out[m].float() - 3.0).abs().max()) == 0.0
+    lib_out = torch.mm(dy, w).double()  # the library's product of the same operands: same values up to a rounding flip here and there
+    assert float(((got - lib_out).abs() > spacing * 1.01).double().mean()) == 0.0
+    assert lib.ctf_policy_fc1_dgrad(ptr(dy), ptr(wt), m + 1, kp, ptr(out), 0, None) != 0   # unsupported shapes say so
+    assert lib.ctf_policy_fc1_dgrad(ptr(dy), ptr(wt), m, kp + 8, ptr(out), 0, None) != 0
+
+
+def test_native_fc1_data_gradient_equals_the_library_path():
+    """CtfPolicyNative.trunk_codes with native_fc1_dgrad: outputs identical; every parameter's gradient equal to the library path's up to
+    bf16 rounding flips of d_act (the conv front's gradients are the ones that see them)."""
+    import copy
+
+    rng = np.random.default_rng(4)
+    g, c, n, b = 15, 14, 8, 2048
+    m = 2 * n + 6
+    codes = torch.tensor((rng.integers(0, c, (b, g, g)) * (rng.random((b, g, g)) < 0.3)).astype(np.uint8), device="cuda")
+    meta = torch.tensor(rng.random((b, m)).astype(np.float32), device="cuda")
+    base = fill_(native.CtfPolicyNative(9, c, g, m)).cuda()
+    outs = []
+    for flag in (True, False):
+        net = copy.deepcopy(base)
+        net.native_fc1_dgrad = flag
+        value, logits = net.trunk_codes(codes, meta)
+        ((logits * torch.linspace(-1, 1, 9, device="cuda")).sum() + (value ** 2).sum()).backward()
+        outs.append((value.detach(), logits.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        a, bgrad = outs[0][2][k].double(), outs[1][2][k].double()
+        assert float((a - bgrad).abs().max()) <= 1e-2 * max(float(bgrad.abs().max()), 1e-6), (k, float((a - bgrad).abs().max()), float(bgrad.abs().max()))
