@@ -414,8 +414,7 @@ class CtfPolicyNative(CtfPolicy):
             )
             if "pf" in m:  # the factored fc1 path (ctf_policy_fc1_patch): W_flat in the view's column order, the per-position fragments, the bias
                 kv = lib.ctf_policy_fact_view_stride(self.grid_size)
-                self._prep.update(fc1_view_wt=self._prep["fc1_w"][:, :kv].t().contiguous(),  # [KV, 256]: the library GEMM's right operand as it is
-                                  fc1_view_w=self._prep["fc1_w"][:, :kv].contiguous(),  # [256, KV]: ctf_policy_view_gemm's
+                self._prep.update(fc1_view_w=self._prep["fc1_w"][:, :kv].contiguous(),  # [256, KV], k-contiguous: the view GEMM's right operand
                                   pf=take(self.fc1.weight.detach().reshape(-1).double(), m["pf"], _TWO_LOG2E, bf),
                                   fc1_b32=(self.fc1.bias.detach().double() * _TWO_LOG2E).to(f32).contiguous())
         return self
@@ -527,8 +526,13 @@ class CtfPolicyNative(CtfPolicy):
                                             ptr(p["b2"]), ptr(b["slot_of"]), ptr(view), ptr(b["prow"]), dev.index, stream), "ctf_policy_features_fact")
             if self.native_view_gemm:  # float32 out either way: the patch product is added before the one rounding
                 ok(lib.ctf_policy_view_gemm(ptr(view), ptr(p["fc1_view_w"]), E, b["kv"], ptr(b["yview"]), dev.index, stream), "ctf_policy_view_gemm")
+            elif E % 4 == 0:
+                # the library's fastest form of this product (tools/view_gemm_forms_probe.py, 65 536 x 4 096: 0.154 ms; the plain
+                # mm(view, W^T stored [KV, 256]) 0.185, mm against the k-contiguous W 0.170): four row ranges as a batch, W k-contiguous
+                torch.bmm(view.view(4, E // 4, b["kv"]), p["fc1_view_w"].t().expand(4, b["kv"], 256), out_dtype=torch.float32,
+                          out=b["yview"].view(4, E // 4, 256))
             else:
-                torch.mm(view, p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"])
+                torch.mm(view, p["fc1_view_w"].t(), out_dtype=torch.float32, out=b["yview"])
 
         if not b.get("placed"):
             # Large allocations on this pool come in two kinds: the slow one costs the front's stores and the GEMM's reads

@@ -76,7 +76,9 @@ def main():
         out["fact_front_x2"] = timed(lambda: [lib.ctf_policy_features_fact(ptr(codes), ptr(meta), ptr(sc), E, N, G, M, arr[t], A, ptr(p["f1"]), ptr(p["b1"]),
                                                                             ptr(p["f2"]), ptr(p["b2"]), ptr(b["slot_of"]), ptr(b["view"]), ptr(b["prow"]), 0, st())
                                               for t in (0, 1)])
-        out["fact_view_gemm_x2"] = timed(lambda: [torch.mm(b["view"], p["fc1_view_wt"], out_dtype=torch.float32, out=b["yview"]) for t in (0, 1)])
+        out["fact_view_gemm_x2"] = timed(lambda: [torch.bmm(b["view"].view(4, E // 4, b["kv"]), p["fc1_view_w"].t().expand(4, b["kv"], 256), out_dtype=torch.float32,
+                                                             out=b["yview"].view(4, E // 4, 256)) for t in (0, 1)])
+        out["fact_view_gemm_plain_mm_x2"] = timed(lambda: [torch.mm(b["view"], p["fc1_view_w"].t(), out_dtype=torch.float32, out=b["yview"]) for t in (0, 1)])
         out["fact_view_gemm_native_x2"] = timed(lambda: [lib.ctf_policy_view_gemm(ptr(b["view"]), ptr(p["fc1_view_w"]), E, b["kv"], ptr(b["yview"]), 0, st()) for t in (0, 1)])
         out["fact_patch_x2"] = timed(lambda: [lib.ctf_policy_fc1_patch(ptr(b["prow"]), ptr(b["row_of_slot"]), ptr(b["work"]), ptr(b["yview"]), ptr(p["pf"]),
                                                                         ptr(p["fc1_b32"]), E, A, G, M, ptr(b["y1"]), 0, st()) for t in (0, 1)])
