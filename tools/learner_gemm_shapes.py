@@ -18,7 +18,7 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if any(k in e.key for k in ("mm", "linear", "matmul", "sum", "index_select", "mul", "_to_copy"))]
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.device_time_total > 0 and (len(sys.argv) > 2 or any(k in e.key for k in ("mm", "linear", "matmul", "sum", "index_select", "mul", "_to_copy")))]
 rows.sort(key=lambda e: -e.device_time_total)
-for e in rows[:28]:
+for e in rows[:(60 if len(sys.argv) > 2 else 28)]:
     print(f"{e.key:28s} {e.device_time_total / 1e3:8.3f} ms  x{e.count:<3d} {str(e.input_shapes)[:150]}")
