@@ -12,10 +12,15 @@ opponent) x num_envs, ray.get): here one process per GPU, each owning a contiguo
 One "step" = one pass of the hot path over one batch: GridworldCtf.step() for every env of the shard
 plus the N observations + metadata rows a rollout consumes (reference ppo.py:59-98), with auto-reset at
 episode end — the two launches of ctf_step_observe (k_step, whose tail blocks regenerate the MT19937 blocks the
-envs have used up, then the render).  About six of the timed steps issue them as ctf_step + ctf_observe instead, so
-that a HIP event can sit between the two for the per-kernel durations.  Workload at N=1: BASELINE.json configs[2] — 8_arena
+envs have used up, then the render).  The timed region holds nothing else: `--windows` (5) back-to-back windows of
+exactly K such steps, each bracketed by barrier + synchronize, MAX over ranks per window; `ms_per_step` / `value` are
+those of the MEDIAN window (`windows_ms` lists them all).  The per-kernel durations come from SAMPLE_STEPS (12) further
+steps AFTER the windows, issued as ctf_step + ctf_observe with a HIP event around each launch, net of the cost of an
+empty event pair measured in the same run (`event_pair_overhead_ms`).  Workload at N=1: BASELINE.json configs[2] — 8_arena
 (arena_iii, 4v4, the reference's 15x15 map), 65 536 envs resident in HBM; N>1 keeps 65 536 envs per GPU
-(weak scaling), envs sharded by global index with no data-path collective (--rollout-exchange adds an
+(weak scaling) in the headline and adds, as `secondary.configs3_262144`, BASELINE.json configs[3] at its own size
+(262 144 envs GLOBAL = 262 144 / N per GPU: the strong-scaling reading of the same path); the N=1 line carries that
+configuration's per-GPU shard of an 8-GPU job as `secondary.arena_32768`.  Envs are sharded by global index with no data-path collective (--rollout-exchange adds an
 asynchronous RCCL all-gather of the compact rollout tensors once per 16-step chunk, what a centralised
 learner would need).  Inputs (Philox action streams for every timed step) are generated on the device
 before the timed region.
@@ -138,6 +143,22 @@ WORKLOADS = {
 }
 
 
+def _cpu_quota():
+    """CPUs the container's cgroup lets this process use at once (cgroup v2 cpu.max or v1 cfs quota / period), None if unlimited or
+    unreadable.  A 1-GPU box shows all 256 logical CPUs in the affinity mask and throttles the process to its own share of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // per)
+    except (OSError, ValueError):
+        return None
+
+
 def _host_cpu():
     model = "unknown"
     try:
@@ -147,7 +168,7 @@ def _host_cpu():
                 break
     except OSError:
         pass
-    return {"model": model, "logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    return {"model": model, "logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": _cpu_quota()}
 
 
 def cpu_baseline(pkg, kwargs, budget_s=12.0):
@@ -169,6 +190,20 @@ def cpu_baseline(pkg, kwargs, budget_s=12.0):
         oracle.run_batch(cfg, batch, steps, 1_000_003 + done_envs, 7, True, cores)
         done_envs += batch
     dt = time.perf_counter() - t0
+    # the same on ALL host cores this process may use: the affinity mask, capped by the cgroup's CPU quota (round 5's
+    # first box: 256 CPUs in the mask, 256 threads = 1.4 M env-steps/s against 3.2 M with 16 — the box throttles to its 16-core share)
+    all_cores = min(len(os.sched_getaffinity(0)), _cpu_quota() or 1 << 30)
+    all_cores_value = all_cores_sample = None
+    if all_cores > cores and not os.environ.get("CTF_BENCH_CPU_THREADS"):
+        b2, d2 = all_cores * 16, 0
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < budget_s / 2:
+            oracle.run_batch(cfg, b2, steps, 2_000_003 + d2, 7, True, all_cores)
+            d2 += b2
+        dt2 = time.perf_counter() - t1
+        all_cores_value, all_cores_sample = d2 * steps / dt2, f"{d2} envs x {steps} steps ({dt2:.1f} s)"
+    elif all_cores == cores:
+        all_cores_value, all_cores_sample = done_envs * steps / dt, "the same run: `cores` is the whole affinity mask"
     out = {
         "value": done_envs * steps / dt,
         "unit": "env-steps/s",
@@ -176,6 +211,9 @@ def cpu_baseline(pkg, kwargs, budget_s=12.0):
         "kind": "port",
         "sample": f"{done_envs} envs x {steps} steps, 8_arena step()+observe(), C oracle, OpenMP over envs ({dt:.1f} s)",
         "single_core_value": one,
+        "all_cores_value": all_cores_value,
+        "all_cores": all_cores,
+        "all_cores_sample": all_cores_sample,
         "host_cpu": _host_cpu(),
     }
     try:  # the per-env Python/NumPy restatement on one core: calibrates this box against BASELINE.md's 1.2 k env-steps/s
@@ -185,6 +223,66 @@ def cpu_baseline(pkg, kwargs, budget_s=12.0):
     except ImportError:
         pass
     return out
+
+
+def facade_1env(pkg, kwargs, device, budget_s=4.0):
+    """The boundary's DROP-IN mode, measured: the reference's own class API (marl-ctf-development_amd.GridworldCtf, a batch of one
+    env behind it) driven exactly as ppo.py:59-98 drives the reference's — per env step N x (standardise_state + get_env_metadata) then
+    step(actions), the process-global `random` / `np.random` contract ON (both generators' states go to the device and come back at
+    every step) — in env-steps/s, to read beside cpu_baseline.python_numpy_1core and BASELINE.md's 1.2 k for the reference itself."""
+    import random
+
+    import numpy as np
+
+    random.seed(42)
+    np.random.seed(42)
+    env = pkg.GridworldCtf(device=device, **kwargs)
+    n = env.N_AGENTS
+    rng = np.random.default_rng(1234)  # an independent action stream: the env's own generators are not perturbed
+
+    def episode_steps(count):
+        for _ in range(count):
+            for i in range(n):
+                env.standardise_state(i, reverse_grid=env.AGENT_TEAMS[i] == 1)
+                env.get_env_metadata(i)
+            _, _, done = env.step([int(a) for a in rng.integers(0, 9, n)])
+            if done:
+                env.reset()
+
+    episode_steps(20)  # warm-up
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        episode_steps(50)
+        steps += 50
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "steps": steps, "us_per_env_step": dt / steps * 1e6,
+            "workload": f"GridworldCtf (reference API, 1 env) on 8_arena: per step {n} x (standardise_state + get_env_metadata) + step(), "
+                        "global-RNG contract on, reset at done — the call pattern of ppo.py:59-98",
+            "reference_python_same_pattern": "1.2 k env-steps/s (BASELINE.md, build container, 1 core); cpu_baseline.python_numpy_1core is "
+                                             "the per-env NumPy restatement on THIS box"}
+
+
+def selfplay_at_reference_length(torch, device, wall_so_far_s, need_gb=90.0, wall_limit_s=120.0):
+    """BASELINE configs[4] on one GPU at the reference's rollout length (num_steps = 500, 8_arena.py:73-74, ppo.py:288): one PPO
+    iteration of 65 536 envs x 500 steps (44 GB of compact rollout, ~78 GB peak).  Guarded: it runs only with >= need_gb GB of free
+    device memory and while the bench has used < wall_limit_s of wall time; otherwise a `skipped` record says why."""
+    torch.cuda.empty_cache()
+    free_gb = torch.cuda.mem_get_info(device)[0] / 1e9
+    if free_gb < need_gb:
+        return {"skipped": f"free device memory {free_gb:.1f} GB < {need_gb:.0f} GB"}
+    if wall_so_far_s > wall_limit_s:
+        return {"skipped": f"bench wall time so far {wall_so_far_s:.0f} s > {wall_limit_s:.0f} s"}
+    try:
+        import bench_rollout
+
+        t0 = time.perf_counter()
+        res = bench_rollout.run(envs=65536, steps=500, device=device, order="device")
+        res["wall_s"] = time.perf_counter() - t0
+        return res
+    except Exception as exc:  # a secondary must never cost the headline line
+        return {"error": repr(exc)}
+    finally:
+        torch.cuda.empty_cache()
 
 
 def stagger_phases(vec, torch, lo, period=500):
@@ -199,67 +297,91 @@ def stagger_phases(vec, torch, lo, period=500):
     torch.cuda.synchronize()
 
 
+SAMPLE_STEPS = 12  # steps run AFTER the timed windows with an event around each launch (the per-kernel durations)
+
+
 def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_metrics=True, stagger=True, gather=None, dist=None,
-                 extras=True, rng_mode="mt19937"):
-    """-> dict of this rank's measurements of one workload (timed region = K calls of step_observe)."""
+                 extras=True, rng_mode="mt19937", windows=5, env_lo=None):
+    """-> dict of this rank's measurements of one workload.
+
+    Timed region: `windows` back-to-back windows, each EXACTLY K calls of ctf_step_observe and nothing else (no event records, no
+    host reads), bracketed by barrier + synchronize on both sides.  The per-kernel durations are taken afterwards, in SAMPLE_STEPS
+    further steps of the same trajectory issued as ctf_step + ctf_observe with an event around each launch and one empty event
+    pair per step (what a pair costs by itself in this stream state: subtracted from the raw figures)."""
+    import numpy as np
+
     sh = pkg.sharding
     label, make_kwargs = WORKLOADS[name]
     kwargs = make_kwargs(pkg)
     device = torch.device("cuda", local_rank)
-    lo = rank * E
+    lo = rank * E if env_lo is None else int(env_lo)
     seeds = sh.env_seeds(run, lo, lo + E)
     vec = pkg.VecGridworldCtf(E, device=local_rank, py_seeds=seeds, np_seeds=seeds, log_metrics=log_metrics, rng_mode=rng_mode, **kwargs)
     N, G, C = vec.N_AGENTS, vec.GRID_SIZE, vec.N_CHANNELS
-    actions = torch.empty((W + K, E, N), dtype=torch.int8, device=device)
-    for t in range(W + K):
-        vec.random_actions(actions[t], seed=0xC7F, step=t, env_offset=lo)
+    actions = torch.empty((max(W, K, SAMPLE_STEPS), E, N), dtype=torch.int8, device=device)
+
+    def fill(first, count):  # the Philox action streams of steps [first, first + count), generated outside every timed region
+        for i in range(count):
+            vec.random_actions(actions[i], seed=0xC7F, step=first + i, env_offset=lo)
+
     vec.observe()  # allocates (and places) the observation buffer
     if stagger:
         stagger_phases(vec, torch, lo, kwargs["GAME_STEPS"])
     observe_kernel = vec.observe_kernel()  # the library's own answer for this buffer (ctf_observe_kernel)
 
-    def one_step(t, events=None):
+    def one_step(i, t):
         if gather is not None:
             vec.rewards, vec.done = gather.views(t)
-        if events:  # a sampled step: the two launches apart, an event around each
-            events[0].record()
-            vec.step(actions[t], auto_reset=True)
-            events[1].record()
-            vec.observe()
-            events[2].record()
-        else:       # the same two launches through one call of the C ABI (ctf_step_observe)
-            vec.step_observe(actions[t], auto_reset=True)
+        vec.step_observe(actions[i], auto_reset=True)  # the two launches through one call of the C ABI (ctf_step_observe)
         if gather is not None:
             gather.step_done(t)  # closes a chunk every 16th step: issued after the render, it runs beside the next step kernel
 
-    for t in range(W):
-        one_step(t)
+    fill(0, W)
+    for i in range(W):
+        one_step(i, i)
     if gather is not None:
         gather.wait()
-    # per-kernel durations: HIP events around the two launches of a SAMPLE of the timed steps (every stride-th one, about six
-    # in all) — an event record costs ~3 us of stream time, three per step were 2.7 % of the arena step
-    stride = max(1, K // 6)
-    ev = {t: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for t in range(stride // 2, K, stride)}
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(K):
-        one_step(W + t, ev.get(t))
-    if gather is not None:
-        gather.flush(W + K)
-        gather.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    t, win = W, []
+    for _ in range(max(1, windows)):
+        fill(t, K)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            one_step(i, t + i)
+        if gather is not None:
+            gather.flush(t + K)
+            gather.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        win.append(time.perf_counter() - t0)
+        t += K
     status = vec.status()
-    import numpy as np
 
-    step_all = np.array([e[0].elapsed_time(e[1]) for e in ev.values()])
-    obs_all = np.array([e[1].elapsed_time(e[2]) for e in ev.values()])
-    out = dict(name=name, label=label, E=E, N=N, G=G, C=C, K=K, W=W, elapsed=elapsed, status=status, observe_kernel=observe_kernel,
+    # ---- after the timed region: per-kernel durations
+    fill(t, SAMPLE_STEPS)
+    if gather is not None:
+        vec.rewards, vec.done = gather.views(0)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(SAMPLE_STEPS)]
+    for i, e in enumerate(ev):
+        e[0].record()
+        vec.step(actions[i], auto_reset=True)
+        e[1].record()
+        vec.observe()
+        e[2].record()
+        e[3].record()  # (e[2], e[3]): an empty pair
+    torch.cuda.synchronize()
+    pair = float(np.median([e[2].elapsed_time(e[3]) for e in ev]))
+    step_raw = np.array([e[0].elapsed_time(e[1]) for e in ev])
+    obs_raw = np.array([e[1].elapsed_time(e[2]) for e in ev])
+    step_all, obs_all = np.maximum(step_raw - pair, 0.0), np.maximum(obs_raw - pair, 0.0)
+    out = dict(name=name, label=label, E=E, N=N, G=G, C=C, K=K, W=W, windows=win, env_lo=lo, status=status | vec.status(),
+               observe_kernel=observe_kernel,
                k_step_ms=float(step_all.mean()), k_observe_ms=float(obs_all.mean()),
+               k_step_raw_ms=float(step_raw.mean()), k_observe_raw_ms=float(obs_raw.mean()), event_pair_ms=pair,
                k_step_p=[float(x) for x in np.percentile(step_all, [10, 50, 90])],
                k_observe_p=[float(x) for x in np.percentile(obs_all, [10, 50, 90])],
                kernel_timing_samples=len(ev), placement_probe_ms=vec.placement_probe_ms, placement_fill_ms=vec.placement_fill_ms,
@@ -267,10 +389,11 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     if extras:
         # outside the timed region: the same env-step with the observation in compact form (ctf_observe_codes: one byte per
         # cell instead of C one-hot bytes — what the GPU policy path consumes)
+        fill(t + SAMPLE_STEPS, K)
         torch.cuda.synchronize()
         tc = time.perf_counter()
-        for t in range(K):
-            vec.step(actions[W + t], auto_reset=True)
+        for i in range(K):
+            vec.step(actions[i], auto_reset=True)
             vec.observe_codes()
         torch.cuda.synchronize()
         out["compact_rate"] = E * K / (time.perf_counter() - tc)
@@ -282,20 +405,54 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     return out
 
 
-def dryrun_workload(pkg, name, E, K, W, rank, dist):
+def dryrun_workload(pkg, name, E, K, W, rank, dist, windows=5, env_lo=None):
     """CTF_BENCH_DRYRUN: the shape of run_workload's result with no kernel behind it (each rank 'takes' 1 + rank ms per step, so the
     max-over-ranks rule is visible in the line)."""
     label, make_kwargs = WORKLOADS[name]
     kwargs = make_kwargs(pkg)
     cfg, derived = pkg.config.build_config(kwargs, log_metrics=True)
-    if dist is not None:
-        dist.barrier()
-    elapsed = K * 1e-3 * (1 + rank)
-    if dist is not None:
-        dist.barrier()
-    return dict(name=name, label=label, E=E, N=cfg.n_agents, G=cfg.grid_size, C=cfg.n_channels, K=K, W=W, elapsed=elapsed, status=0,
-                observe_kernel="none (dry run)", k_step_ms=0.25, k_observe_ms=0.75, k_step_p=[0.25] * 3, k_observe_p=[0.75] * 3,
+    win = []
+    for w in range(max(1, windows)):
+        if dist is not None:
+            dist.barrier()
+        win.append(K * 1e-3 * (1 + rank) * (1 + 0.01 * abs(w - 2)))  # window 2 is the fastest; the median of five is window 1 or 3
+        if dist is not None:
+            dist.barrier()
+    return dict(name=name, label=label, E=E, N=cfg.n_agents, G=cfg.grid_size, C=cfg.n_channels, K=K, W=W, windows=win,
+                env_lo=rank * E if env_lo is None else env_lo, status=0,
+                observe_kernel="none (dry run)", k_step_ms=0.25, k_observe_ms=0.75, k_step_raw_ms=0.25, k_observe_raw_ms=0.75,
+                event_pair_ms=0.0, k_step_p=[0.25] * 3, k_observe_p=[0.75] * 3,
                 kernel_timing_samples=0, placement_probe_ms=None, placement_fill_ms=None, placement=None, kwargs=kwargs)
+
+
+def reduce_windows(sh, r, device, world, use_dist):
+    """The timing rule: per window the MAX over ranks; the line reports the MEDIAN window.  Adds to r: `windows_max` (s),
+    `elapsed` (s, the median window), `my_ms` (this rank's own median window, ms per step)."""
+    import statistics
+
+    r["windows_max"] = sh.max_over_ranks_list(r["windows"], device, world if not use_dist else max(world, 2))
+    r["elapsed"] = statistics.median(r["windows_max"])
+    r["my_ms"] = statistics.median(r["windows"]) / r["K"] * 1e3
+    return r
+
+
+def workload_block(r, value, traffic_table, n_gpus=1):
+    """The fields every measured workload carries (headline and secondaries alike)."""
+    N, G, C, K = r["N"], r["G"], r["C"], r["K"]
+    return {
+        "value": value, "unit": "env-steps/s", "steps": K, "windows": len(r["windows_max"]), "ms_per_step": r["elapsed"] / K * 1e3,
+        "windows_ms_per_step": [w / K * 1e3 for w in r["windows_max"]],
+        "roofline": roofline_of(r, traffic_table),
+        "whole_step_hbm_frac": env_step_algorithmic_bytes(N, C, G) * value / n_gpus / 1e9 / HBM_PEAK_GBS,
+        "kernels_ms": {"k_step": r["k_step_ms"], r["observe_kernel"]: r["k_observe_ms"]},
+        "kernels_ms_raw_events": {"k_step": r["k_step_raw_ms"], r["observe_kernel"]: r["k_observe_raw_ms"]},
+        "event_pair_overhead_ms": r["event_pair_ms"],
+        "kernels_ms_p10_p50_p90": {"k_step": r["k_step_p"], r["observe_kernel"]: r["k_observe_p"]},
+        "kernel_timing_samples": r["kernel_timing_samples"],
+        "kernel_timing": f"{r['kernel_timing_samples']} steps AFTER the timed windows, ctf_step + ctf_observe with a HIP event around each "
+                         "launch, net of an empty event pair (event_pair_overhead_ms); the timed windows hold ctf_step_observe only",
+        "placement": r["placement"], "placement_probe_ms": r["placement_probe_ms"], "device_status_bits": r["status"],
+    }
 
 
 def roofline_of(r, traffic_table):
@@ -337,6 +494,9 @@ def main():
                     help="also all-gather the compact rollout tensors (rewards, done) over RCCL, once per 16-step chunk, for a "
                          "centralised learner; off by default: env shards are independent and a data-parallel learner needs no exchange")
     ap.add_argument("--run", type=int, default=1, help="seed family: env seeds are 1_000_003*run + global env index")
+    ap.add_argument("--windows", type=int, default=5, help="back-to-back timed windows of --steps steps each; the line reports the median one")
+    ap.add_argument("--configs3-envs", type=int, default=262144,
+                    help="GLOBAL env count of the N>1 secondary (BASELINE.json configs[3]: 262 144 envs over the N GPUs)")
     args = ap.parse_args()
 
     rc = world_or_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -383,6 +543,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
     n_gpus = world
     E, K, W = args.envs_per_gpu, args.steps, args.warmup
+    t_start = time.perf_counter()
 
     # The path shards with NO data-path collective: envs are independent, every rank steps and renders its own shard, and a
     # data-parallel learner consumes the observations where they are.  --rollout-exchange adds the hand-off a centralised
@@ -390,17 +551,32 @@ def main():
     # async) once per 16 steps.
     exchange = use_dist and args.rollout_exchange
     n_agents = len(WORKLOADS[args.workload][1](pkg)["AGENT_CONFIG"])
-    gather = sh.ChunkedRolloutGather(E, n_agents, device, world, chunk=16, force_collective=exchange) if exchange else None
-    if dryrun:
-        r = dryrun_workload(pkg, args.workload, E, K, W, rank, dist)
-    else:
-        r = run_workload(pkg, torch, args.workload, E, K, W, rank, local_rank, world, args.run, log_metrics=not args.no_metrics,
-                         stagger=not args.no_stagger, gather=gather, dist=dist, extras=(rank == 0))
-    my_ms = r["elapsed"] / K * 1e3
-    elapsed = sh.max_over_ranks(r["elapsed"], device, world if not use_dist else max(world, 2))
-    ranks_seen, per_rank_ms = sh.gather_rank_times(rank, my_ms, world if use_dist else 1)
+
+    def measure(name, e_rank, k, env_lo=None, use_gather=False, extras=False, rng_mode="mt19937"):
+        """One workload on EVERY rank of the job (a collective call: barriers inside) -> this rank's record with the job-wide
+        window times (reduce_windows)."""
+        g = sh.ChunkedRolloutGather(e_rank, n_agents, device, world, chunk=16, force_collective=exchange) if use_gather else None
+        if dryrun:
+            r = dryrun_workload(pkg, name, e_rank, k, W, rank, dist, windows=args.windows, env_lo=env_lo)
+        else:
+            r = run_workload(pkg, torch, name, e_rank, k, W, rank, local_rank, world, args.run, log_metrics=not args.no_metrics,
+                             stagger=not args.no_stagger, gather=g, dist=dist, extras=extras, rng_mode=rng_mode, windows=args.windows,
+                             env_lo=env_lo)
+        return reduce_windows(sh, r, device, world, use_dist)
+
+    r = measure(args.workload, E, K, use_gather=exchange, extras=(rank == 0))
+    elapsed = r["elapsed"]
+    ranks_seen, per_rank_ms = sh.gather_rank_times(rank, r["my_ms"], world if use_dist else 1)
     # a multi-GPU line must verify itself: every rank of the job reported a time, exactly once
     ranks_ok = sh.ranks_complete(ranks_seen, per_rank_ms, n_gpus)
+
+    # BASELINE.json configs[3] at ITS OWN size: 262 144 envs GLOBAL, sharded by global env index over the N ranks of this job
+    # (strong scaling: 262 144 / N per GPU; 32 768 at N = 8).  Every rank runs it (barriers inside), rank 0 reports it.
+    r3 = None
+    if world > 1 and args.workload == "arena" and not args.no_secondary:
+        lo3, hi3 = sh.shard_range(args.configs3_envs, rank, world)
+        r3 = measure("arena", hi3 - lo3, max(20, min(K, 100)), env_lo=lo3)
+        r3["shards"] = [list(sh.shard_range(args.configs3_envs, q, world)) for q in range(world)]
 
     if rank == 0:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -431,13 +607,16 @@ def main():
                 "ranks_share_one_device": bool(os.environ.get("CTF_BENCH_ONE_DEVICE")),
                 "rollout_exchange": ("RCCL all-gather of rewards+done per 16-step chunk, async" if exchange else
                                      "none: env shards are independent (data-parallel learner)"),
+                "timed_region": f"{len(r['windows_max'])} back-to-back windows of exactly {K} ctf_step_observe calls (nothing else inside), "
+                                "barrier + synchronize on both sides of each, MAX over ranks per window; value / ms_per_step = the MEDIAN window",
             },
-            "roofline": roofline_of(r, traffic_table),
-            "whole_step_hbm_frac": env_step_algorithmic_bytes(N, C, G) * value / n_gpus / 1e9 / HBM_PEAK_GBS,
-            "kernels_ms": {"k_step": r["k_step_ms"], r["observe_kernel"]: r["k_observe_ms"]},
-            "kernels_ms_p10_p50_p90": {"k_step": r["k_step_p"], r["observe_kernel"]: r["k_observe_p"]},
-            "kernel_timing_samples": r["kernel_timing_samples"],
-            "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (r["k_step_ms"] * 1e-3) / 1e9,
+        }
+        blk = workload_block(r, value, traffic_table, n_gpus)
+        for k in ("windows", "windows_ms_per_step", "roofline", "whole_step_hbm_frac", "kernels_ms", "kernels_ms_raw_events",
+                  "event_pair_overhead_ms", "kernels_ms_p10_p50_p90", "kernel_timing_samples", "kernel_timing"):
+            line[k] = blk[k]
+        line.update({
+            "step_kernel_gbs": step_algorithmic_bytes(N, G) * E / (r["k_step_ms"] * 1e-3) / 1e9 if r["k_step_ms"] > 0 else None,
             "episode_phase_spread": r.get("episode_phase_spread"),
             # where the observation buffer landed: a box whose allocations are all of the slow kind explains its
             # own lower number here — kind, the render's time over a plain fill of the same buffer, the slowest candidate seen
@@ -450,40 +629,53 @@ def main():
             "per_rank_ms_per_step": [per_rank_ms[ranks_seen.index(k)] for k in sorted(ranks_seen)],
             "compact_observation": {"env_steps_per_s_per_gpu": r.get("compact_rate"), "obs_bytes_per_env": N * G * G + N * (2 * N + 6) * 2,
                                     "note": "step() + observe_codes(); not the headline metric (the reference's consumers take the one-hot planes)"},
-        }
+        })
+        sec = {}
+        if r3 is not None:
+            g3 = args.configs3_envs
+            v3 = g3 * r3["K"] / r3["elapsed"]
+            b3 = workload_block(r3, v3, traffic_table, n_gpus)
+            b3.update({
+                "workload": f"BASELINE.json configs[3]: {r3['label']}, {g3} envs GLOBAL sharded by global env index over {n_gpus} GPUs "
+                            f"({r3['E']} on rank 0), no data-path collective",
+                "global_envs": g3, "envs_per_gpu": [hi - lo for lo, hi in r3["shards"]], "shards": r3["shards"], "n_gpus": n_gpus,
+                "scaling": "strong",
+            })
+            sec[f"configs3_{g3}"] = b3
         if n_gpus == 1 and not args.no_secondary and args.workload == "arena" and not dryrun:
-            sec = {}
-            for name, e2 in (("arena20", 65536), ("split", 4096)):
-                k2 = max(20, min(K, 100))
-                r2 = run_workload(pkg, torch, name, e2, k2, W, 0, local_rank, 1, args.run, log_metrics=not args.no_metrics,
-                                  stagger=not args.no_stagger)
-                v2 = e2 * k2 / r2["elapsed"]
-                sec[f"{name}_{e2}"] = {
-                    "workload": f"{r2['label']}, {e2} envs", "value": v2, "unit": "env-steps/s", "steps": k2, "ms_per_step": r2["elapsed"] / k2 * 1e3,
-                    "roofline": roofline_of(r2, traffic_table),
-                    "whole_step_hbm_frac": env_step_algorithmic_bytes(r2["N"], r2["C"], r2["G"]) * v2 / 1e9 / HBM_PEAK_GBS,
-                    "kernels_ms": {"k_step": r2["k_step_ms"], r2["observe_kernel"]: r2["k_observe_ms"]},
-                    "placement": r2["placement"], "placement_probe_ms": r2["placement_probe_ms"], "device_status_bits": r2["status"],
-                }
+            # (a) the per-GPU shard of configs[3] on an 8-GPU node — 32 768 envs, created here as "rank 3 of 8" (global envs
+            # [98 304, 131 072)); (b) the synthetic 20x20 arena; (c) configs[1], 0_the_split at 4 096 envs
+            for key, name, e2, lo2 in (("arena_32768", "arena", 32768, 3 * 32768), ("arena20_65536", "arena20", 65536, None),
+                                       ("split_4096", "split", 4096, None)):
+                r2 = measure(name, e2, max(20, min(K, 100)), env_lo=lo2)
+                v2 = e2 * r2["K"] / r2["elapsed"]
+                b2 = workload_block(r2, v2, traffic_table)
+                b2["workload"] = f"{r2['label']}, {e2} envs" + (
+                    f" = the shard of rank 3 of 8 of BASELINE.json configs[3] (262 144 envs global; global envs [{lo2}, {lo2 + e2}))"
+                    if lo2 is not None else "")
+                sec[key] = b2
             # SURVEY 8(a)'s opt-in counter-based RNG (ctf_env.h CTF_RNG_COUNTER): the same workload with Philox streams in place of
             # the reference's two MT19937 generators — a secondary, never the headline (its trajectories are not the reference's)
-            rc = run_workload(pkg, torch, "arena", E, max(20, min(K, 100)), W, 0, local_rank, 1, args.run, log_metrics=not args.no_metrics,
-                              stagger=not args.no_stagger, extras=False, rng_mode="counter")
-            sec["arena_65536_counter_rng"] = {
-                "workload": f"{rc['label']}, {E} envs, rng_mode=counter (Philox4x32-10 streams; parity: the oracle reading the same tape)",
-                "value": E * rc["K"] / rc["elapsed"], "unit": "env-steps/s", "steps": rc["K"], "ms_per_step": rc["elapsed"] / rc["K"] * 1e3,
-                "kernels_ms": {"k_step": rc["k_step_ms"], rc["observe_kernel"]: rc["k_observe_ms"]}, "placement": rc["placement"],
-                "device_status_bits": rc["status"],
-            }
+            rc = measure("arena", E, max(20, min(K, 100)), rng_mode="counter")
+            bc = workload_block(rc, E * rc["K"] / rc["elapsed"], traffic_table)
+            bc["workload"] = f"{rc['label']}, {E} envs, rng_mode=counter (Philox4x32-10 streams; parity: the oracle reading the same tape)"
+            sec["arena_65536_counter_rng"] = bc
+            try:  # the boundary's drop-in mode: the reference's own GridworldCtf API driven as ppo.py:59-98 drives it, one env
+                sec["facade_1env"] = facade_1env(pkg, r["kwargs"], local_rank)
+            except Exception as exc:
+                sec["facade_1env"] = {"error": repr(exc)}
             try:  # BASELINE configs[4] on one GPU: self-play rollout (env + two policy networks) + the reference's PPO update
                 import bench_rollout
 
                 sec["ppo_selfplay_65536x16"] = bench_rollout.run(envs=65536, steps=16, device=local_rank, order="device")
             except Exception as exc:  # a secondary must never cost the headline line
                 sec["ppo_selfplay_65536x16"] = {"error": repr(exc)}
+            sec["ppo_selfplay_65536x500"] = selfplay_at_reference_length(torch, local_rank, time.perf_counter() - t_start)
+        if sec:
             line["secondary"] = sec
         if n_gpus == 1 and not args.no_cpu_baseline and not dryrun:
             line["cpu_baseline"] = cpu_baseline(pkg, r["kwargs"])
+        line["wall_s"] = time.perf_counter() - t_start
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:

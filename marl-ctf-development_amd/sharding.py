@@ -271,3 +271,18 @@ def max_over_ranks(value, device, world):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def max_over_ranks_list(values, device, world):
+    """Element-wise MAX over ranks of a list of python floats (bench.py: one entry per timed window)."""
+    vals = [float(v) for v in values]
+    if world == 1:
+        return vals
+    import torch
+    import torch.distributed as dist
+
+    if dist.get_backend() == "gloo":
+        device = "cpu"
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.cpu()]

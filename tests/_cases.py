@@ -95,3 +95,22 @@ def view_arrays(v, n, g):
         metrics=np.array([[v.metrics[k][i] for i in range(n)] for k in range(abi.N_METRICS)], np.int32),
         visitation=np.stack([np.frombuffer(v.visitation[i], np.uint8, g * g).reshape(g, g) for i in range(n)]).copy(),
     )
+
+
+def spawn_edge_kwargs():
+    """Both spawn positions on row 0 / column 0 with the inner line of the (clipped) respawn window walled off: EVERY respawn draws an
+    offset whose "- 1" (gridworld_ctf.py:775, the WARNING at :773) goes negative.  Two scouts of 1 hp start next to each other with
+    TAG_PROBABILITY = 1: whoever moves first in step 1 tags the other one out."""
+    rows = (".......",
+            ".###...",
+            ".......",
+            ".#.....",
+            ".#.....",
+            ".#.....",
+            ".......")
+    blocks = [(r, c) for r in range(7) for c in range(7) if rows[r][c] == "#"]
+    scen = dict(SCENARIO_NAME="SpawnEdge0", GRID_SIZE=7, FLIP_AXIS=None, FLAG_POSITIONS={0: (2, 6), 1: (6, 6)},
+                CAPTURE_POSITIONS={0: (2, 6), 1: (6, 6)}, SPAWN_POSITIONS={0: (0, 2), 1: (4, 0)},
+                AGENT_STARTING_POSITIONS={0: (3, 3), 1: (3, 4)}, BLOCK_TILE_SLICES=blocks, DESTRUCTIBLE_TILE_SLICES=[])
+    return dict(GRID_SIZE=7, AGENT_CONFIG={0: {"team": 0, "type": 0}, 1: {"team": 1, "type": 0}}, GAME_STEPS=50, MAP_SYMMETRY_CHECK=False,
+                TAG_PROBABILITY=1.0, AGENT_TYPE_HP={0: 1, 1: 1, 2: 1, 3: 1}, AGENT_TYPE_DAMAGE={0: 1, 1: 1, 2: 1, 3: 1}, SCENARIO=scen)

@@ -293,6 +293,9 @@ def run_case(Ref, scn, case):
     print(f"{case['name']:24s} N={n} G={G} C={C} T={T} {os.path.getsize(path)//1024:5d} KiB  "
           f"tags={ev['tag_count']} respawns={ev['respawn_tag_count']} pickups={ev['flag_pickups']} caps={ev['flag_captures']} "
           f"disp={ev['flag_dispossessions']} laid={ev['blocks_laid']} mined={ev['blocks_mined']} rsum={arrays['rewards'].sum():.2f}")
+    ev.update(team_captures=meta_json["team_captures"], bytes=os.path.getsize(path), path=path,
+              min_pos=int(arrays["pos"].min()) if T else 0)
+    return ev
 
 
 def main():

@@ -30,10 +30,33 @@ def test_gpus_2_without_torchrun_starts_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["ranks_ok"] is True
-    assert line["per_rank_ms_per_step"] == [1.0, 2.0] and line["ms_per_step"] == 2.0  # the MAX over ranks
+    # five timed windows, per window the MAX over ranks (rank r 'takes' 1 + r ms per step, window w 1 + |w - 2| % more); the line
+    # reports the MEDIAN window, not the best one and not the mean
+    assert line["windows"] == 5 and line["windows_ms_per_step"] == pytest.approx([2.04, 2.02, 2.0, 2.02, 2.04])
+    assert line["per_rank_ms_per_step"] == pytest.approx([1.01, 2.02]) and line["ms_per_step"] == pytest.approx(2.02)
     assert line["config"]["global_envs"] == 2 * line["config"]["envs_per_gpu"]
-    assert line["value"] == pytest.approx(2 * 65536 / 2e-3)
+    assert line["value"] == pytest.approx(2 * 65536 / 2.02e-3)
     assert "DRY RUN" in line["data"]  # a dry-run line can never pass for a measurement
+    assert line["kernels_ms"]["k_step"] + line["kernels_ms"]["none (dry run)"] <= line["ms_per_step"]
+
+
+def test_gpus_2_line_carries_configs3_at_its_own_global_size():
+    """BASELINE.json configs[3] is 262 144 envs GLOBAL: besides the weak-scaling headline (65 536 per GPU) an N-rank line holds
+    `secondary.configs3_262144`, 262 144 / N envs per rank, sharded by global env index (sharding.shard_range)."""
+    r = _run("bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    c3 = _one_json_line(r.stdout)["secondary"]["configs3_262144"]
+    assert c3["global_envs"] == 262144 and c3["envs_per_gpu"] == [131072, 131072] and c3["shards"] == [[0, 131072], [131072, 262144]]
+    assert c3["scaling"] == "strong" and c3["n_gpus"] == 2 and "configs[3]" in c3["workload"] and "262144 envs GLOBAL" in c3["workload"]
+    assert c3["value"] == pytest.approx(262144 / (c3["ms_per_step"] * 1e-3)) and c3["ms_per_step"] == pytest.approx(2.02)
+    assert c3["roofline"]["algorithmic_bytes_per_env"] == 25878
+    # an odd global size is split by the same rule the learner and the tests use
+    r = _run("bench.py", "--gpus", "2", "--steps", "2", "--warmup", "0", "--configs3-envs", "1001")
+    c3 = _one_json_line(r.stdout)["secondary"]["configs3_1001"]
+    assert c3["envs_per_gpu"] == [501, 500] and c3["global_envs"] == 1001
+    # N = 1 is not configs[3]: no such block (its shard rides as secondary.arena_32768 on a GPU)
+    r = _run("bench.py", "--gpus", "1", "--steps", "2", "--warmup", "0")
+    assert "secondary" not in _one_json_line(r.stdout)
 
 
 def test_gpus_1_is_one_rank_in_process():

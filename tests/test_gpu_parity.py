@@ -346,35 +346,40 @@ def _digest_rows(t2d, w, mask=None, chunk=2048):
     return out
 
 
-@pytest.mark.parametrize("workload", ["arena", "arena20"])
-def test_every_env_of_the_benchs_state_matches_the_oracle(workload):
+@pytest.mark.parametrize("workload,E,lo", [("arena", 65536, 0), ("arena20", 65536, 0), ("arena", 32768, 3 * 32768)])
+def test_every_env_of_the_benchs_state_matches_the_oracle(workload, E, lo):
     """What bench.py times, checked on ALL 65 536 envs: its own protocol (bench.stagger_phases: a discarded first episode, masked
     resets that leave the envs at staggered episode phases, ~131 envs auto-reset per step) and then 32 step_observe(auto_reset)
     steps, against the OpenMP oracle running the same protocol env by env (oracle.bench_digest).  Compared per env and per
     step: the float64 rewards' bit patterns, done, the whole observation block and the metadata rows (as 64-bit weighted
     sums), and at the end both MT19937 states, env_step_count and the capture counters.  The render runs through
-    ctf_step_observe, i.e. with the ring regeneration on the side stream beside it."""
+    ctf_step_observe, i.e. with the ring regeneration on the side stream beside it.
+
+    The third case is BASELINE.json configs[3]'s per-GPU shard — 262 144 envs global over 8 GPUs = 32 768 envs — created exactly as
+    bench.py's rank 3 of 8 creates it (and as `secondary.arena_32768` of the N=1 line does): seeds and action streams are functions
+    of the GLOBAL env index, envs [98 304, 131 072); the staggering phase is the local index, as in bench.stagger_phases."""
     import bench
 
-    E, steps, period = 65536, 32, 500
+    steps, period = 32, 500
     kw = _workload(workload)
-    seeds = pkg.sharding.env_seeds(1, 0, E)
+    seeds = pkg.sharding.env_seeds(1, lo, lo + E)
+    assert (lo, lo + E) == ((0, E) if lo == 0 else pkg.sharding.shard_range(262144, 3, 8))
     vec = pkg.VecGridworldCtf(E, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=True, tune_placement=False, **kw)
     cfg, _ = cfgmod.build_config(kw, log_metrics=True)
     import os, time
 
     t0 = time.perf_counter()
-    want = oracle.bench_digest(cfg, seeds, 0, period, 0x5747, steps, 0xC7F, min(len(os.sched_getaffinity(0)), 16))
+    want = oracle.bench_digest(cfg, seeds, lo, period, 0x5747, steps, 0xC7F, min(len(os.sched_getaffinity(0)), 16))
     t_cpu = time.perf_counter() - t0
     vec.observe()
-    bench.stagger_phases(vec, torch, 0, period)
+    bench.stagger_phases(vec, torch, lo, period)
     N, dev = vec.N_AGENTS, vec.device
     wt = lambda n: torch.from_numpy(oracle.digest_weights(n).view(np.int64)).to(dev)
     w_obs, w_meta, w_rew, w_rng = wt(vec.obs[0].numel()), wt(N * vec.META_LEN), wt(N), wt(625)
     acts = torch.empty((E, N), dtype=torch.int8, device=dev)
     i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
     for t in range(steps):
-        vec.random_actions(acts, seed=0xC7F, step=t, env_offset=0)
+        vec.random_actions(acts, seed=0xC7F, step=t, env_offset=lo)
         rewards, done, obs, meta = vec.step_observe(acts, auto_reset=True, want_f64=True)
         bad = (_digest_rows(obs.view(E, -1), w_obs) != i64(want["obs"][t])).nonzero()
         assert bad.numel() == 0, f"{workload} step {t}: observation of envs {bad[:8].flatten().tolist()} ({bad.numel()} in all)"
@@ -387,7 +392,7 @@ def test_every_env_of_the_benchs_state_matches_the_oracle(workload):
     _, caps, nsteps = vec.counters()
     assert np.array_equal(nsteps.cpu().numpy(), want["misc"][:, 0]) and np.array_equal(caps.cpu().numpy(), want["misc"][:, 1:])
     assert vec.status() == 0
-    print(f"\n{workload}: all {E} envs x {steps} steps equal the oracle; oracle {t_cpu:.1f} s on the host cores")
+    print(f"\n{workload}: all {E} envs (global [{lo}, {lo + E})) x {steps} steps equal the oracle; oracle {t_cpu:.1f} s on the host cores")
     vec.close()
 
 
@@ -578,6 +583,32 @@ def test_status_bits_for_bad_action_and_action_mask():
     want = np.array([[1] * 5 + ([0] * 4 if vec.AGENT_TYPES[i] in (0, 1) else [1] * 4) for i in range(case.n)], np.uint8)
     assert np.array_equal(mask, want)
     vec.close()
+
+
+def test_spawn_edge_status_bit_and_the_facades_index_error():
+    """The documented difference from the reference: a respawn offset that goes negative (spawn on row / column 0,
+    gridworld_ctf.py:773-785) sets CTF_ST_SPAWN_EDGE — same state as the oracle — and the drop-in facade raises IndexError."""
+    from _cases import spawn_edge_kwargs
+
+    kw = spawn_edge_kwargs()
+    cfg, _ = cfgmod.build_config(kw, log_metrics=True)
+    seeds = np.arange(8, dtype=np.uint64) + 5
+    vec = pkg.VecGridworldCtf(8, device=_dev(), py_seeds=seeds, np_seeds=seeds, **kw)
+    acts = torch.full((8, 2), 4, dtype=torch.int8, device=vec.device)
+    vec.step(acts)
+    assert vec.status() == abi.ST_SPAWN_EDGE
+    for e in range(8):
+        ref = oracle.OracleEnv(cfg)
+        ref.seed(int(seeds[e]), int(seeds[e]))
+        _, _, st = ref.step(np.array([4, 4], np.int8))
+        assert st == abi.ST_SPAWN_EDGE
+        _state_equal(view_arrays(vec.get_state(e), 2, 7), view_arrays(ref.get_state(), 2, 7), f"env {e}")
+    vec.close()
+    random.seed(5)
+    np.random.seed(5)
+    env = pkg.GridworldCtf(**kw)
+    with pytest.raises(IndexError):
+        env.step([4, 4])
 
 
 def test_facade_is_a_drop_in_for_the_reference_api():

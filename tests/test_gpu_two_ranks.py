@@ -33,7 +33,13 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert line["device_status_bits"] == 0 and len(line["per_rank_ms_per_step"]) == 2 and min(line["per_rank_ms_per_step"]) > 0
     assert line["ms_per_step"] >= max(line["per_rank_ms_per_step"]) * 0.999   # the MAX over ranks (the barrier adds to it, never subtracts)
     assert line["value"] == pytest.approx(2 * 8192 * 40 / (line["ms_per_step"] * 40e-3), rel=1e-6)
-    assert "secondary" not in line and "cpu_baseline" not in line                # those are N = 1 blocks
+    assert "cpu_baseline" not in line and set(line["secondary"]) == {"configs3_262144"}   # the N = 1 blocks are absent
+    assert len(line["windows_ms_per_step"]) == 5 and sorted(line["windows_ms_per_step"])[2] == pytest.approx(line["ms_per_step"])
+    # BASELINE configs[3] at its own size: 262 144 envs global = 131 072 per rank here, sharded by global env index
+    c3 = line["secondary"]["configs3_262144"]
+    assert c3["global_envs"] == 262144 and c3["envs_per_gpu"] == [131072, 131072] and c3["scaling"] == "strong"
+    assert c3["device_status_bits"] == 0 and c3["value"] == pytest.approx(262144 / (c3["ms_per_step"] * 1e-3), rel=1e-6)
+    assert c3["roofline"]["kernel"] in ("k_observe_tiles", "k_observe") and 0 < c3["roofline"]["frac"] < 1
 
 
 def test_selfplay_iteration_with_two_ranks_on_one_gpu():

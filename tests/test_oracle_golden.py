@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle
-from _cases import Case, case_names, view_arrays
+from _cases import Case, abi, case_names, cfgmod, spawn_edge_kwargs, view_arrays
 
 
 @pytest.mark.parametrize("name", case_names())
@@ -70,3 +70,23 @@ def test_f64_to_f16_matches_numpy():
     want = xs.astype(np.float16).view(np.uint16)
     got = np.array([oracle.f64_to_f16_bits(x) for x in xs], np.uint16)
     assert np.array_equal(got, want)
+
+
+def test_a_respawn_offset_that_goes_negative_raises_the_spawn_edge_bit():
+    """The one place where this build deliberately does NOT follow the reference ("differences"): a spawn position
+    on row 0 / column 0 whose respawn draws an offset of 0 makes the reference store the coordinate -1 (gridworld_ctf.py:775-785; its
+    own "WARNING" at :773) and carry on with NumPy's negative-index wrap.  Here the step reports CTF_ST_SPAWN_EDGE (the facade raises
+    IndexError) and the agent sits on the wrapped cell G - 1.  Respawns on such a map whose "- 1" stays >= 0 (the agent lands one cell
+    up / left of the open cell drawn) DO follow the reference: tests/golden/fuzz_edge0_*.npz."""
+    kw = spawn_edge_kwargs()
+    cfg, _ = cfgmod.build_config(kw, log_metrics=True)
+    env = oracle.OracleEnv(cfg)
+    env.seed(5, 5)
+    rewards, done, status = env.step(np.array([4, 4], np.int8))
+    assert status == abi.ST_SPAWN_EDGE
+    s = view_arrays(env.get_state(), 2, 7)
+    respawned = 0 if s["pos"][0].tolist() != [3, 3] else 1
+    assert s["metrics"][abi.METRIC_NAMES.index("respawn_tag_count")].sum() >= 1
+    r, c = s["pos"][respawned]
+    assert (r == 6 and respawned == 0) or (c == 6 and respawned == 1)  # the wrapped row / column
+    assert s["grid"][r, c] == 4 + 4 * respawned  # the agent's tile is where NumPy's wrap would have written it
