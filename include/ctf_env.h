@@ -238,6 +238,28 @@ int ctf_action_mask(const ctf_env* env, uint8_t* mask_host);
 int ctf_get_state(ctf_env* env, int32_t env_index, ctf_state_view* host_out);
 int ctf_set_state(ctf_env* env, int32_t env_index, const ctf_state_view* host_in);
 
+/* ONE env step for a caller that lives in HOST memory: the batch-of-one mode behind the reference's own class API, i.e. what a
+ * rollout loop over GridworldCtf does per step (ppo.py:59-98): step(actions) (gridworld_ctf.py:849-918), then standardise_state(i) +
+ * get_env_metadata(i) for every agent (:975-1069), with the process-global generators handed in and back (random.getstate() /
+ * np.random.get_state(); the reference draws from them inside step).  For a handle of n_envs == 1 (CTF_E_INVALID otherwise).
+ * Everything — the hand-over of both generator states, the step, the render, the state read-back — is enqueued on `stream` behind
+ * ONE host-to-device and in front of ONE device-to-host copy of a staging block the handle owns (pinned on the host side), and the
+ * call waits for the stream once: round 5 measured 408 us per env step for the same work through ctf_set_rng_states + ctf_step +
+ * ctf_get_rng_states + ctf_observe + ctf_get_state + ctf_status with a wait behind each.
+ * All pointers are HOST pointers; any OUT pointer may be NULL (not wanted).
+ *   actions_host    int8 [N], or NULL: no step is made (state, observation and generator states are still returned: reset())
+ *   py_mt625_in / np_mt625_in   uint32 [625] (624 words + position) to install BEFORE the step, or NULL (keep the device's)
+ *   reverse_mask, flags         as ctf_observe / ctf_step
+ *   rewards_host    double [N] (the reference's Python floats, bit-exact)      done_host    int32
+ *   status_host     the sticky CTF_ST_* bits raised since the last read (cleared, like ctf_status)
+ *   view_host       the env's state after the step (ctf_get_state's view)
+ *   py_mt625_out / np_mt625_out uint32 [625]: the generators AFTER the step, standard form
+ *   obs_host        uint8 [N][C][G][G]      meta_host   IEEE binary16 bits [N][M] */
+int ctf_host_step(ctf_env* env, const int8_t* actions_host, const uint32_t* py_mt625_in, const uint32_t* np_mt625_in,
+                  uint32_t reverse_mask, uint32_t flags, double* rewards_host, int32_t* done_host, uint32_t* status_host,
+                  ctf_state_view* view_host, uint32_t* py_mt625_out, uint32_t* np_mt625_out, uint8_t* obs_host, uint16_t* meta_host,
+                  void* stream);
+
 /* Bulk export of the counters the duel / evaluation harness reads (utils.py:557-571, metrics_logger.py:137-159):
  *   metrics_dev   int32 [E][13][N] agent-level counters (CTF_M_* order) or NULL (zeros when log_metrics == 0)
  *   captures_dev  int32 [E][2]     metrics['team_flag_captures'] or NULL

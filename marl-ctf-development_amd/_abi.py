@@ -130,6 +130,8 @@ SYMBOLS = {
     "ctf_action_mask": (C.c_int, [_P, _P]),
     "ctf_get_state": (C.c_int, [_P, C.c_int32, C.POINTER(CtfStateView)]),
     "ctf_set_state": (C.c_int, [_P, C.c_int32, C.POINTER(CtfStateView)]),
+    "ctf_host_step": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
+                                C.POINTER(CtfStateView), _P, _P, _P, _P, _P]),
     "ctf_export_counters": (C.c_int, [_P, _P, _P, _P, _P]),
     "ctf_status": (C.c_int, [_P, C.POINTER(C.c_uint32), _P]),
     "ctf_random_actions": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),

@@ -5,6 +5,7 @@
 // No torch, no C++ types across the boundary, no CPU implementation of the path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -38,7 +39,39 @@ struct ctf_env {
     uint64_t* seed_scratch;  // device, 2*E u64
     uint32_t* rng_scratch;   // device, 2 x 625 u32: one env's two generators in the standard form (ctf_set/get_rng_state)
     uint32_t step_phase;     // counts the step launches (k_step's tail blocks: which share of the stale rings this launch takes)
+    // ctf_host_step (n_envs == 1): one device block + its pinned host twin, allocated on first use
+    uint8_t* hio_dev;
+    uint8_t* hio_host;
 };
+
+// Layout of the ctf_host_step block (byte offsets; every segment 16-byte aligned, the observation 256-byte aligned).
+struct HostIo {
+    size_t actions, py_in, np_in, in_end;                               // host -> device
+    size_t out, rw64, done_status, py_out, np_out, obs, meta, grid, rec, metrics, vis, vislog, end;  // device -> host
+};
+static size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static HostIo host_io_layout(const DevCfg& d) {
+    HostIo L;
+    const size_t mt = up((CTF_MT_N + 1) * 4, 16);
+    L.actions = 0;
+    L.py_in = 16;
+    L.np_in = L.py_in + mt;
+    L.in_end = L.np_in + mt;
+    L.out = up(L.in_end, 256);
+    L.rw64 = L.out;
+    L.done_status = L.rw64 + CTF_MAX_AGENTS * 8;
+    L.py_out = L.done_status + 16;
+    L.np_out = L.py_out + mt;
+    L.obs = up(L.np_out + mt, 256);
+    L.meta = L.obs + up((size_t)d.obs_bytes, 16);
+    L.grid = L.meta + up((size_t)d.N * d.M * 2, 16);
+    L.rec = L.grid + (size_t)d.GS;
+    L.metrics = L.rec + (size_t)d.RS;
+    L.vis = L.metrics + up((size_t)CTF_N_METRICS * d.N * 4, 16);
+    L.vislog = L.vis + (d.log_metrics ? (size_t)d.N * d.GS * 4 : 0);
+    L.end = L.vislog + (d.log_metrics ? (size_t)CTF_VIS_LOG * d.N * 2 : 0);
+    return L;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -85,6 +118,8 @@ static void free_all(ctf_env* h) {
     (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
     (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch); (void)hipFree(h->p.rngready);
     (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib);
+    if (h->hio_dev) (void)hipFree(h->hio_dev);
+    if (h->hio_host) (void)hipHostFree(h->hio_host);
     delete h;
 }
 
@@ -105,6 +140,8 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     h->seed_scratch = nullptr;
     h->rng_scratch = nullptr;
     h->step_phase = 0;
+    h->hio_dev = nullptr;
+    h->hio_host = nullptr;
     h->cfg = *cfg; h->d = d; h->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
@@ -337,50 +374,69 @@ extern "C" int ctf_action_mask(const ctf_env* h, uint8_t* mask_host) {
     return CTF_OK;
 }
 
+// rec / grid / metrics bytes of one env -> the scalar part of its host view
+static void decode_record(const DevCfg& d, const uint8_t* grid, const uint8_t* rec, const int32_t* metrics, ctf_state_view* out, int32_t misc[4]) {
+    memset(out, 0, sizeof(*out));
+    memcpy(out->grid, grid, (size_t)d.GG);
+    for (int i = 0; i < d.N; i++) {
+        memcpy(&out->hp[i], rec + 8 * i, 8);
+        out->pos[i][0] = (int8_t)rec[d.off_pos + 2 * i];
+        out->pos[i][1] = (int8_t)rec[d.off_pos + 2 * i + 1];
+        out->has_flag[i] = rec[d.off_flag + i];
+        out->perm[i] = rec[d.off_perm + i];
+        int16_t inv;
+        memcpy(&inv, rec + d.off_inv + 2 * i, 2);
+        out->inventory[i] = inv;
+    }
+    memcpy(misc, rec + d.off_misc, 16);
+    out->step_count = misc[0];
+    out->team_captures[0] = misc[1];
+    out->team_captures[1] = misc[2];
+    out->done = (misc[3] & CTF_F_DONE) ? 1 : 0;
+    if (metrics)
+        for (int k = 0; k < CTF_N_METRICS; k++)
+            for (int i = 0; i < d.N; i++) out->metrics[k][i] = metrics[(size_t)k * d.N + i];
+}
+
+// visitation maps = base maps (or zeros + 1 at the start cells while nothing has been folded) + the `count` log entries
+// of steps (folded, step_count] (entries[r][i] = agent i's cell after step folded + 1 + r); u8 wrap as in the reference
+static void decode_visitation(const DevCfg& d, const int32_t misc[4], std::vector<uint32_t>& v, const uint16_t* entries, int count,
+                              ctf_state_view* out) {
+    if (misc[3] & CTF_F_BASE_ZERO) {
+        std::fill(v.begin(), v.end(), 0u);
+        for (int i = 0; i < d.N; i++) v[(size_t)i * d.GS + d.start_pos[i][0] * d.G + d.start_pos[i][1]] = 1;  // reset(): :473
+    }
+    for (int r = 0; r < count; r++)
+        for (int i = 0; i < d.N; i++) {
+            const uint16_t cell = entries[(size_t)r * d.N + i];
+            if (cell < (uint16_t)d.GG) v[(size_t)i * d.GS + cell]++;
+        }
+    for (int i = 0; i < d.N; i++)
+        for (int k = 0; k < d.GG; k++) out->visitation[i][k] = (uint8_t)(v[(size_t)i * d.GS + k] & 0xFFu);
+}
+
 extern "C" int ctf_get_state(ctf_env* h, int32_t e, ctf_state_view* out) {
     if (!h || !out) return fail(CTF_E_INVALID, "null argument");
     if (e < 0 || e >= h->d.n_envs) return fail(CTF_E_RANGE, "env index %d", e);
     DeviceGuard guard(h->device);
     const DevCfg& d = h->d;
     HIP_TRY(hipDeviceSynchronize());
-    memset(out, 0, sizeof(*out));
     std::vector<uint8_t> rec((size_t)d.RS), grid((size_t)d.GS);
     HIP_TRY(hipMemcpy(grid.data(), h->p.grid + (size_t)e * d.GS, (size_t)d.GS, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(rec.data(), h->p.rec + (size_t)e * d.RS, (size_t)d.RS, hipMemcpyDeviceToHost));
-    memcpy(out->grid, grid.data(), (size_t)d.GG);
-    for (int i = 0; i < d.N; i++) {
-        memcpy(&out->hp[i], rec.data() + 8 * i, 8);
-        out->pos[i][0] = (int8_t)rec[d.off_pos + 2 * i];
-        out->pos[i][1] = (int8_t)rec[d.off_pos + 2 * i + 1];
-        out->has_flag[i] = rec[d.off_flag + i];
-        out->perm[i] = rec[d.off_perm + i];
-        int16_t inv;
-        memcpy(&inv, rec.data() + d.off_inv + 2 * i, 2);
-        out->inventory[i] = inv;
-    }
-    int32_t misc[4];
-    memcpy(misc, rec.data() + d.off_misc, 16);
-    out->step_count = misc[0];
-    out->team_captures[0] = misc[1];
-    out->team_captures[1] = misc[2];
-    out->done = (misc[3] & CTF_F_DONE) ? 1 : 0;
-    if (d.log_metrics) {
-        std::vector<int32_t> m((size_t)CTF_N_METRICS * d.N);
+    std::vector<int32_t> m((size_t)CTF_N_METRICS * d.N);
+    if (d.log_metrics)
         HIP_TRY(hipMemcpy(m.data(), h->p.metrics + (size_t)e * CTF_N_METRICS * d.N, m.size() * 4, hipMemcpyDeviceToHost));
-        for (int k = 0; k < CTF_N_METRICS; k++)
-            for (int i = 0; i < d.N; i++) out->metrics[k][i] = m[(size_t)k * d.N + i];
-        // visitation maps = base maps (or zeros + 1 at the start cells while nothing has been folded) + the log
-        // entries of steps (folded, step_count]; u8 wrap as in the reference
+    int32_t misc[4];
+    decode_record(d, grid.data(), rec.data(), d.log_metrics ? m.data() : nullptr, out, misc);
+    if (d.log_metrics) {
         std::vector<uint32_t> v((size_t)d.N * d.GS, 0);
-        if (misc[3] & CTF_F_BASE_ZERO) {
-            for (int i = 0; i < d.N; i++) v[(size_t)i * d.GS + d.start_pos[i][0] * d.G + d.start_pos[i][1]] = 1;  // reset(): :473
-        } else {
+        if (!(misc[3] & CTF_F_BASE_ZERO))
             HIP_TRY(hipMemcpy(v.data(), h->p.vis + (size_t)e * d.N * d.GS, v.size() * 4, hipMemcpyDeviceToHost));
-        }
         const int folded = misc[3] >> CTF_F_FOLDED_SHIFT;
         const int count = misc[0] - folded;  // <= CTF_VIS_LOG - 1 entries, slots (folded+1 .. step) mod 512
+        std::vector<uint16_t> entries((size_t)(count > 0 ? count : 0) * d.N);
         if (count > 0) {
-            std::vector<uint16_t> entries((size_t)count * d.N);
             const size_t pitch = (size_t)d.n_envs * d.N * 2, width = (size_t)d.N * 2;
             int done_rows = 0;
             while (done_rows < count) {  // at most two runs: the ring may wrap
@@ -391,14 +447,106 @@ extern "C" int ctf_get_state(ctf_env* h, int32_t e, ctf_state_view* out) {
                                     hipMemcpyDeviceToHost));
                 done_rows += rows;
             }
-            for (int r = 0; r < count; r++)
-                for (int i = 0; i < d.N; i++) {
-                    const uint16_t cell = entries[(size_t)r * d.N + i];
-                    if (cell < (uint16_t)d.GG) v[(size_t)i * d.GS + cell]++;
-                }
         }
-        for (int i = 0; i < d.N; i++)
-            for (int k = 0; k < d.GG; k++) out->visitation[i][k] = (uint8_t)(v[(size_t)i * d.GS + k] & 0xFFu);
+        decode_visitation(d, misc, v, entries.data(), count > 0 ? count : 0, out);
+    }
+    return CTF_OK;
+}
+
+// ---- ctf_host_step: one env, host memory on both sides ------------------------------------------------------------------------
+// Gathers what a host view of env 0 needs (grid, record, counters, visitation base maps and log) next to the step's outputs, so
+// that ONE device-to-host copy brings everything back; reads and clears the sticky status word.
+__global__ void __launch_bounds__(256) k_host_pack(DevCfg d, DevPtrs p, uint8_t* io, HostIo L) {
+    const int t = threadIdx.x;
+    for (int k = t; k < d.GS; k += 256) io[L.grid + k] = p.grid[k];
+    for (int k = t; k < d.RS; k += 256) io[L.rec + k] = p.rec[k];
+    if (d.log_metrics) {
+        uint32_t* m = (uint32_t*)(io + L.metrics);
+        for (int k = t; k < CTF_N_METRICS * d.N; k += 256) m[k] = (uint32_t)p.metrics[k];
+        uint32_t* v = (uint32_t*)(io + L.vis);
+        for (int k = t; k < d.N * d.GS; k += 256) v[k] = p.vis[k];
+        uint32_t* lg = (uint32_t*)(io + L.vislog);
+        const uint32_t* src = (const uint32_t*)p.vislog;  // n_envs == 1: the ring [512][N] u16 is contiguous, N even or odd: 512 * N * 2 bytes
+        for (int k = t; k < CTF_VIS_LOG * d.N / 2; k += 256) lg[k] = src[k];
+    }
+    if (t == 0) {
+        uint32_t* ds = (uint32_t*)(io + L.done_status);
+        ds[1] = *p.status;
+        *p.status = 0;
+    }
+}
+
+extern "C" int ctf_host_step(ctf_env* h, const int8_t* actions, const uint32_t* py_in, const uint32_t* np_in, uint32_t reverse_mask,
+                             uint32_t flags, double* rewards, int32_t* done, uint32_t* status, ctf_state_view* view, uint32_t* py_out,
+                             uint32_t* np_out, uint8_t* obs, uint16_t* meta, void* stream) {
+    if (!h) return fail(CTF_E_INVALID, "null handle");
+    if (h->d.n_envs != 1) return fail(CTF_E_INVALID, "ctf_host_step serves a handle of ONE env (this one has %d): batches use ctf_step / ctf_observe", h->d.n_envs);
+    const bool rng_io = py_in || np_in || py_out || np_out;
+    if (rng_io)
+        if (int rc = need_mode(h, CTF_RNG_MT19937, "ctf_host_step with generator states")) return rc;
+    for (const uint32_t* s : {py_in, np_in})
+        if (s && s[CTF_MT_N] > CTF_MT_N) return fail(CTF_E_INVALID, "MT position %u > 624", s[CTF_MT_N]);
+    DeviceGuard guard(h->device);
+    const DevCfg& d = h->d;
+    const HostIo L = host_io_layout(d);
+    if (!h->hio_dev) {
+        if (hipMalloc((void**)&h->hio_dev, L.end) != hipSuccess) return fail(CTF_E_NOMEM, "hipMalloc(%zu) failed", L.end);
+        if (hipHostMalloc((void**)&h->hio_host, L.end, hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(h->hio_dev);
+            h->hio_dev = nullptr;
+            return fail(CTF_E_NOMEM, "hipHostMalloc(%zu) failed", L.end);
+        }
+        HIP_TRY(hipMemset(h->hio_dev, 0, L.end));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *hd = h->hio_dev, *hh = h->hio_host;
+    // host -> device: actions and the generator states to install, one copy
+    if (actions) memcpy(hh + L.actions, actions, (size_t)d.N);
+    if (py_in) memcpy(hh + L.py_in, py_in, (CTF_MT_N + 1) * 4);
+    if (np_in) memcpy(hh + L.np_in, np_in, (CTF_MT_N + 1) * 4);
+    if (actions || py_in || np_in) HIP_TRY(hipMemcpyAsync(hd, hh, L.in_end, hipMemcpyHostToDevice, st));
+    if (py_in || np_in) {
+        HIP_TRY(ctf_launch_import_rng(d, h->p, py_in ? (const uint32_t*)(hd + L.py_in) : nullptr,
+                                      np_in ? (const uint32_t*)(hd + L.np_in) : nullptr, 0, 1, st));
+        HIP_TRY(ctf_launch_rng_refill(d, h->p, 0, 1, 1, st));
+        HIP_TRY(rng_fresh(h, st));
+    }
+    if (actions)
+        HIP_TRY(ctf_launch_step(d, h->p, (const int8_t*)(hd + L.actions), nullptr, (double*)(hd + L.rw64), hd + L.done_status, flags,
+                                h->step_phase++, 1, st));
+    if (py_out || np_out)
+        HIP_TRY(ctf_launch_export_rng(d, h->p, py_out ? (uint32_t*)(hd + L.py_out) : nullptr, np_out ? (uint32_t*)(hd + L.np_out) : nullptr,
+                                      0, 1, st));
+    if (obs || meta)
+        HIP_TRY(ctf_launch_observe(d, h->p, obs ? hd + L.obs : nullptr, meta ? (uint16_t*)(hd + L.meta) : nullptr,
+                                   resolve_reverse(h, reverse_mask), h->n_cus, st));
+    hipLaunchKernelGGL(k_host_pack, dim3(1), dim3(256), 0, st, d, h->p, hd, L);
+    HIP_TRY(hipGetLastError());
+    // device -> host: everything in one copy; the only wait of the call
+    HIP_TRY(hipMemcpyAsync(hh + L.out, hd + L.out, L.end - L.out, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (rewards && actions) memcpy(rewards, hh + L.rw64, (size_t)d.N * 8);
+    const uint32_t* ds = (const uint32_t*)(hh + L.done_status);
+    if (status) *status = ds[1];
+    if (py_out) memcpy(py_out, hh + L.py_out, (CTF_MT_N + 1) * 4);
+    if (np_out) memcpy(np_out, hh + L.np_out, (CTF_MT_N + 1) * 4);
+    if (obs) memcpy(obs, hh + L.obs, (size_t)d.obs_bytes);
+    if (meta) memcpy(meta, hh + L.meta, (size_t)d.N * d.M * 2);
+    int32_t misc[4];
+    ctf_state_view local;
+    ctf_state_view* out = view ? view : &local;
+    decode_record(d, hh + L.grid, hh + L.rec, d.log_metrics ? (const int32_t*)(hh + L.metrics) : nullptr, out, misc);
+    if (done) *done = out->done;
+    if (view && d.log_metrics) {
+        std::vector<uint32_t> v((size_t)d.N * d.GS);
+        memcpy(v.data(), hh + L.vis, v.size() * 4);
+        const int folded = misc[3] >> CTF_F_FOLDED_SHIFT;
+        const int count = misc[0] - folded;
+        std::vector<uint16_t> entries((size_t)(count > 0 ? count : 0) * d.N);
+        const uint16_t* ring = (const uint16_t*)(hh + L.vislog);
+        for (int r = 0; r < count; r++)
+            memcpy(entries.data() + (size_t)r * d.N, ring + (size_t)((folded + 1 + r) & (CTF_VIS_LOG - 1)) * d.N, (size_t)d.N * 2);
+        decode_visitation(d, misc, v, entries.data(), count > 0 ? count : 0, out);
     }
     return CTF_OK;
 }

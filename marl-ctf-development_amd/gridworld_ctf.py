@@ -332,6 +332,23 @@ class VecGridworldCtf:
                                               _abi.STEP_AUTO_RESET if auto_reset else 0, self._stream()), self._lib)
         return self.rewards, self.done, self.obs, self.meta
 
+    def host_step(self, actions=None, py_in=None, np_in=None, reverse_mask=None, rng_out=False, view=None, obs=None, meta=None):
+        """ctf_host_step (a handle of ONE env): everything in host memory, one round trip to the device.  actions: int8 numpy [N]
+        or None (no step); py_in / np_in: uint32 numpy [625] to install before the step; -> (rewards float64 [N], done, status
+        bits, view, py_out, np_out) with obs (uint8 [N, C, G, G]) and meta (float16 [N, M]) filled in place when given."""
+        n = self.N_AGENTS
+        rm = _abi.REVERSE_DEFAULT if reverse_mask is None else int(reverse_mask) & ((1 << n) - 1)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        rewards = np.zeros(n, np.float64)
+        done, status = C.c_int32(0), C.c_uint32(0)
+        view = view if view is not None else _abi.CtfStateView()
+        py_out = np.empty(625, np.uint32) if rng_out else None
+        np_out = np.empty(625, np.uint32) if rng_out else None
+        _abi.check(self._lib.ctf_host_step(self._h, ptr(actions), ptr(py_in), ptr(np_in), rm, 0, ptr(rewards), C.byref(done),
+                                           C.byref(status), C.byref(view), ptr(py_out), ptr(np_out), ptr(obs), ptr(meta),
+                                           self._stream()), self._lib)
+        return rewards, bool(done.value), status.value, view, py_out, np_out
+
     def random_actions(self, out, seed, step, env_offset=0):
         """Fill ``out`` (int8 [E, N]) with the synthetic Philox action stream of bench.py / the tests."""
         a = self._check_dev(out, _torch().int8, self.n_envs * self.N_AGENTS)
@@ -452,6 +469,12 @@ class GridworldCtf:
         self.grid = np.zeros((self.GRID_SIZE, self.GRID_SIZE), dtype=np.uint8)  # live array, updated in place
         self.has_flag = np.zeros(self.N_AGENTS, dtype=np.uint8)
         self._obs_cache = None
+        c, g, n = len(self.TILES_USED) + 1, self.GRID_SIZE, self.N_AGENTS
+        self._obs_host = np.zeros((n, c, g, g), dtype=np.uint8)        # filled by every ctf_host_step round trip
+        self._meta_host = np.zeros((n, 2 * n + 6), dtype=np.float16)
+        self._rng_in = np.empty((2, 625), dtype=np.uint32)
+        self._default_mask = self._default_reverse_mask()
+        self._py_last = self._np_last = None  # the generator states the last step wrote back to random / np.random
         self.reset()
 
     # -- pickling / deepcopy (Ray hands the env to workers by value) ------------------------------
@@ -472,8 +495,8 @@ class GridworldCtf:
         return new
 
     # -- host mirror of the device state --------------------------------------------------------
-    def _pull(self):
-        v = self._vec.get_state(0)
+    def _mirror(self, v):
+        """The reference's attributes from a state view (the same round trip has refreshed _obs_host / _meta_host)."""
         n, g = self.N_AGENTS, self.GRID_SIZE
         self.grid[...] = np.frombuffer(v.grid, dtype=np.uint8, count=g * g).reshape(g, g)
         self.agent_positions = {i: (int(v.pos[i][0]), int(v.pos[i][1])) for i in range(n)}
@@ -484,7 +507,12 @@ class GridworldCtf:
         self.env_step_count = int(v.step_count)
         self.done = bool(v.done)
         self._view = v
-        self._obs_cache = None
+        self._obs_cache = None  # (renders under a non-default reversal; the default one is _obs_host / _meta_host, always current)
+
+    def _pull(self):
+        """State view + the default observation of the env as it is now, in one round trip (no step)."""
+        _, _, _, v, _, _ = self._vec.host_step(None, obs=self._obs_host, meta=self._meta_host)
+        self._mirror(v)
 
     @property
     def metrics(self):
@@ -517,47 +545,47 @@ class GridworldCtf:
         if self.MAP_SYMMETRY_CHECK:
             assert np.all(self.standardise_state(0) == self.standardise_state(1, reverse_grid=True))
 
-    def _push_global_rng(self):
-        """random / np.random -> the device streams of env 0: one host array, one upload, one stream-ordered launch (no
-        device synchronisation, no per-word copies)."""
-        torch = _torch()
+    def _global_rng_in(self):
+        """random / np.random -> the two uint32 [625] arrays (624 words + position) ctf_host_step installs before the step.
+        -> (np.random's state tuple, unchanged): True when both generators are exactly where the previous step of THIS env left
+        them — the device streams are then already in place and nothing needs to go over."""
         st = np.random.get_state()
-        both = np.empty((2, 625), dtype=np.uint32)
-        both[0] = _py_random.getstate()[1]
+        pt = _py_random.getstate()[1]
+        if self._py_last is not None and pt == self._py_last and st[2] == self._np_last[1] and np.array_equal(st[1], self._np_last[0]):
+            return st, True
+        both = self._rng_in
+        both[0] = pt
         both[1, :624] = st[1]
         both[1, 624] = st[2]
-        dev = torch.from_numpy(both.view(np.int32)).to(self._vec.device)
-        self._vec.set_rng_states(dev[0:1], dev[1:2])
-        return st
-
-    def _pull_global_rng(self, np_state_before):
-        py, npw = self._vec.get_rng_states()
-        both = _torch().cat((py, npw)).cpu().numpy().view(np.uint32)  # the step's only synchronisation
-        _py_random.setstate((3, tuple(int(x) for x in both[0]), None))
-        np.random.set_state((np_state_before[0], both[1, :624].copy(), int(both[1, 624]), np_state_before[3], np_state_before[4]))
+        return st, False
 
     def step(self, actions):
-        torch = _torch()
         acts = [actions[i] for i in range(self.N_AGENTS)]
         for i, a in enumerate(acts):
             if not (isinstance(a, (int, np.integer)) and 0 <= int(a) <= 8):
                 raise KeyError(a)  # ACTION_DELTAS[type][action] in the reference
-        st = self._push_global_rng() if self._rng_mode == "global" else None
-        dev = torch.tensor([[int(a) for a in acts]], dtype=torch.int8, device=self._vec.device)
-        self._vec.step(dev, want_f64=True)
-        rewards = [float(x) for x in self._vec.rewards64[0].cpu().numpy()]
-        status = self._vec.status()
-        if st is not None:
-            self._pull_global_rng(st)
-        self._pull()
+        glob = self._rng_mode == "global"
+        st, in_place = self._global_rng_in() if glob else (None, True)
+        # ONE round trip (ctf_host_step): generator states in, step, render of all N agents, state view and generator states out
+        r64, _, status, v, py, npw = self._vec.host_step(np.array(acts, dtype=np.int8), None if in_place else self._rng_in[0],
+                                                         None if in_place else self._rng_in[1], rng_out=glob, obs=self._obs_host,
+                                                         meta=self._meta_host)
+        if glob:
+            self._py_last = tuple(py.tolist())
+            self._np_last = (npw[:624], int(npw[624]))
+            _py_random.setstate((3, self._py_last, None))
+            np.random.set_state((st[0], npw[:624], int(npw[624]), st[3], st[4]))
+        self._mirror(v)
         if status & _abi.ST_NO_RESPAWN:
             raise ValueError("high <= 0")  # np.random.randint(0) in the reference's respawn
         if status & _abi.ST_SPAWN_EDGE:
             raise IndexError("respawn window clipped at row/col 0: the reference misplaces the agent here")
-        return self.grid, rewards, self.done
+        return self.grid, r64.tolist(), self.done
 
     def _observe(self, reverse_mask):
-        if self._obs_cache is None or self._obs_cache[0] != reverse_mask:
+        if reverse_mask == self._default_mask:
+            return reverse_mask, self._obs_host, self._meta_host
+        if self._obs_cache is None or self._obs_cache[0] != reverse_mask:  # a non-default reversal: its own render
             obs, meta = self._vec.observe(reverse_mask)
             self._obs_cache = (reverse_mask, obs[0].cpu().numpy(), meta[0].cpu().numpy())
         return self._obs_cache
@@ -567,7 +595,7 @@ class GridworldCtf:
 
     def standardise_state(self, agent_idx, reverse_grid=False):
         i = int(agent_idx)
-        mask = self._default_reverse_mask()
+        mask = self._default_mask
         if bool(reverse_grid) != bool((mask >> i) & 1):
             mask ^= 1 << i
         return self._observe(mask)[1][i][None].copy()
@@ -576,8 +604,7 @@ class GridworldCtf:
         for t in self.AGENT_TYPES.values():
             if t not in self.agent_hp:
                 raise KeyError(t)  # the reference indexes agent_hp by type id (gridworld_ctf.py:1041)
-        mask = self._obs_cache[0] if self._obs_cache is not None else self._default_reverse_mask()
-        return self._observe(mask)[2][int(agent_idx)][None].copy()
+        return self._meta_host[int(agent_idx)][None].copy()  # (the metadata rows do not depend on the reversal)
 
     def get_env_dims(self):
         c, g, n = len(self.TILES_USED) + 1, self.GRID_SIZE, self.N_AGENTS
