@@ -35,7 +35,7 @@ def _sync(torch, dist, device):
 
 
 def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update_epochs=4, num_minibatches=4, device=0, micro_batch=1 << 20,
-        rank=0, world=1, dist=None, run_seed=1, order=None, force_dp=False):
+        rank=0, world=1, dist=None, run_seed=1, order=None, force_dp=False, deterministic=None):
     """-> dict: rollout / update / total env-steps per second of one PPO iteration (rollout of `steps` env steps of `envs`
     envs PER RANK, then `update_epochs` x `num_minibatches` minibatch updates over the world * envs * steps * 4 samples)."""
     import torch
@@ -110,7 +110,7 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         del throwaway, adv, ret
         log("warm-up done; timed update ...")
         lrn = learner.PPOLearner(nets[0], vec.N_CHANNELS, world=world, rank=rank, order=order, update_epochs=update_epochs,
-                                 num_minibatches=num_minibatches, force_collective=force_dp)
+                                 num_minibatches=num_minibatches, force_collective=force_dp, deterministic=deterministic)
         _sync(torch, dist, dev)
         t2 = time.perf_counter()
         losses = lrn.update(out, micro_batch=micro)  # (no progress callback: it would read the losses back after every minibatch)
@@ -118,7 +118,7 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
         update_s = sh.max_over_ranks(time.perf_counter() - t2, dev, world)
         res.update({
             "update_s": update_s, "update_samples": world * samples, "update_epochs": update_epochs, "num_minibatches": num_minibatches,
-            "micro_batch": micro, "minibatch_order": lrn.order,
+            "micro_batch": micro, "minibatch_order": lrn.order, "deterministic": lrn.deterministic,
             "update_sample_passes_per_s": world * samples * update_epochs / update_s,
             "value": world * envs * steps / (rollout_s + update_s), "learner_share_of_time": update_s / (rollout_s + update_s),
             "losses_v_pg_entropy": [float(x) for x in losses],
@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=1 << 20, help="samples per forward / backward piece of a minibatch")
     ap.add_argument("--order", choices=["numpy", "device"], default=None, help="minibatch order: np.random.shuffle on the host (the reference's) or "
                     "torch.randperm on the device (default with several ranks)")
+    ap.add_argument("--deterministic", action="store_true", help="fixed-order gradient reductions (PPOLearner(deterministic=True); also CTF_DETERMINISTIC=1)")
     args = ap.parse_args()
 
     import bench  # the launch rule of --gpus N lives there (stdlib only: the launcher never touches HIP)
@@ -218,7 +219,7 @@ def main():
             raise SystemExit("bench_rollout.py needs a GPU: there is no CPU fallback")
         res = run(args.envs, args.steps, args.policy, args.dtype, not args.no_update, args.update_epochs, args.num_minibatches,
                   device=local_rank, micro_batch=args.micro_batch, rank=rank, world=world, dist=dist, order=args.order,
-                  force_dp=dist is not None and world == 1)  # CTF_FORCE_DIST: the N-rank update's collectives over RCCL with one rank
+                  force_dp=dist is not None and world == 1, deterministic=True if args.deterministic else None)  # CTF_FORCE_DIST: the N-rank update's collectives over RCCL with one rank
     if rank == 0:
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:

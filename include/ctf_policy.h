@@ -220,6 +220,17 @@ int ctf_rollout_store_step(const uint8_t* codes_dev, const uint16_t* meta_dev, i
                            float* actions_out, float* logprobs_out, float* values_out, int8_t* env_actions_out, int32_t device_id,
                            void* stream);
 
+/* DETERMINISTIC MODE of the training kernels (the reference's update is deterministic under its seeds, ppo.py:174-242).  The weight / bias
+ * gradient kernels — ctf_policy_front_backward, ctf_policy_front_dgrad (bias gradients), ctf_policy_front_wgrad, ctf_policy_linear_wgrad —
+ * normally end in one float atomicAdd per element and block on the gradient, whose order of arrival differs from run to run.  With a
+ * workspace registered for the device (float32, 16-byte aligned, the caller's, alive until it is unregistered) every block stores its
+ * partial sums in its own slice of the workspace instead, and a second launch adds the slices IN BLOCK ORDER: two identical calls give
+ * bit-identical gradients.  The launches of one device that use the workspace must be stream-ordered (one learner at a time).
+ * 24 M floats (96 MB) cover every launch of the 8_arena network on a 256-CU device; a launch that needs more fails with a message.
+ * workspace_dev = NULL switches the mode off.  ctf_policy_deterministic_workspace: floats registered (0 = off). */
+int ctf_policy_set_deterministic(int32_t device_id, float* workspace_dev, int64_t workspace_floats);
+int64_t ctf_policy_deterministic_workspace(int32_t device_id);
+
 const char* ctf_policy_last_error(void);
 
 #ifdef __cplusplus

@@ -163,6 +163,8 @@ SYMBOLS = {
     "ctf_policy_fc1_dgrad": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "ctf_rollout_store_step": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32),
                                          C.c_int32, _P, _P, _P, _P, C.POINTER(C.c_uint8), C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "ctf_policy_set_deterministic": (C.c_int, [C.c_int32, _P, C.c_int64]),
+    "ctf_policy_deterministic_workspace": (C.c_int64, [C.c_int32]),
     "ctf_policy_last_error": (C.c_char_p, []),
 }
 

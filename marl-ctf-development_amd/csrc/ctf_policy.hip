@@ -631,6 +631,42 @@ int ctf_policy_fail(const char* msg) {
 }
 static int pfail(const char* msg) { return ctf_policy_fail(msg); }
 
+// ---- deterministic mode: the per-device workspace and the ordered reduction of the blocks' partial sums
+static DetWorkspace g_det[64];
+extern "C" int ctf_policy_set_deterministic(int32_t device_id, float* workspace_dev, int64_t workspace_floats) {
+    if (device_id < 0 || device_id >= 64) return pfail("device_id out of range");
+    if (workspace_dev && (workspace_floats < 1 || ((uintptr_t)workspace_dev & 15))) return pfail("workspace: 16-byte aligned, at least one float");
+    g_det[device_id].ptr = workspace_dev;
+    g_det[device_id].floats = workspace_dev ? workspace_floats : 0;
+    return 0;
+}
+extern "C" int64_t ctf_policy_deterministic_workspace(int32_t device_id) {
+    return (device_id >= 0 && device_id < 64 && g_det[device_id].ptr) ? g_det[device_id].floats : 0;
+}
+DetWorkspace ctf_policy_det(int device_id) {
+    if (device_id < 0 || device_id >= 64) return DetWorkspace{nullptr, 0};
+    return g_det[device_id];
+}
+__global__ void __launch_bounds__(256) k_det_reduce(const float* part, int n_blocks, int64_t stride, int elems, float* dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    const float* p = part + i;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 3 < n_blocks; b += 4) {
+        s0 += p[(size_t)b * stride];
+        s1 += p[(size_t)(b + 1) * stride];
+        s2 += p[(size_t)(b + 2) * stride];
+        s3 += p[(size_t)(b + 3) * stride];
+    }
+    for (; b < n_blocks; b++) s0 += p[(size_t)b * stride];
+    dst[i] += (s0 + s1) + (s2 + s3);
+}
+hipError_t ctf_policy_det_reduce(const float* part, int n_blocks, int64_t stride, int elems, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_det_reduce, dim3((elems + 255) / 256), dim3(256), 0, st, part, n_blocks, stride, elems, dst);
+    return hipGetLastError();
+}
+
 // compute units of a device, looked up once per device and thread (hipGetDeviceProperties is not free)
 static int policy_n_cus(int device_id);
 int ctf_policy_cus(int device_id) { return policy_n_cus(device_id); }
@@ -777,10 +813,12 @@ struct DgradArgs {
     float* db2;              // float [32] += , or NULL
     float* db1;              // float [16] += , or NULL
     float* dw2;              // W2 instantiation: float [32][16][9] += conv2's weight gradient (dz2 is then not written at all)
+    float* part;             // deterministic mode: float [blocks][DGRAD_PART] = every block's own (dw2 | db2 | db1), else NULL (atomics)
     int64_t S;
     int32_t Kp;
     uint32_t inv_g1, inv_g2;
 };
+#define DGRAD_PART (32 * 16 * 9 + 32 + 16)
 // W2 = true fuses conv2's WEIGHT gradient into the same pass: dz2 never leaves the CU.  Separate kernels moved, per sample, dz2 out
 // (7.7 KB) and back in (7.7 KB) and h1 in a second time (5.4 KB) — and the weight-gradient kernel, once its transposing stores were
 // gone, ran at the speed of exactly that traffic (0.70 ms per 262 144 samples, 4.9 TB/s).  Both images get the padding the position
@@ -968,7 +1006,8 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
             float t = 0.0f;
             for (int k = 0; k < 256; k++)
                 if (((k & 63) >> 5) == h2) t += red[r * 256 + k];
-            atomicAdd(a.db2 + c, t);
+            if (a.part) a.part[(size_t)blockIdx.x * DGRAD_PART + 32 * 16 * 9 + c] = t;
+            else atomicAdd(a.db2 + c, t);
         }
         __syncthreads();
     }
@@ -981,7 +1020,8 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
             float t = 0.0f;
             for (int k = 0; k < 256; k++)
                 if (((k & 63) >> 4) == gg) t += red[r * 256 + k];
-            atomicAdd(a.db1 + c, t);
+            if (a.part) a.part[(size_t)blockIdx.x * DGRAD_PART + 32 * 16 * 9 + 32 + c] = t;
+            else atomicAdd(a.db1 + c, t);
         }
     }
     if (W2) {  // the block's four partial weight gradients -> one; D tile: lane holds rows m = 4 (lane >> 4) + r of column n = lane & 15
@@ -998,7 +1038,8 @@ __global__ void __launch_bounds__(256) k_policy_front_dgrad(DgradArgs a) {
             float v = 0.0f;
             for (int w = 0; w < wpb; w++) v += red[w * 9 * 32 * 16 + e];
             const int t = e / (32 * 16), oi = e - t * (32 * 16);
-            atomicAdd(a.dw2 + (size_t)oi * 9 + t, v);  // [out][in][tap]
+            if (a.part) a.part[(size_t)blockIdx.x * DGRAD_PART + (size_t)oi * 9 + t] = v;
+            else atomicAdd(a.dw2 + (size_t)oi * 9 + t, v);  // [out][in][tap]
         }
     }
 }
@@ -1037,7 +1078,11 @@ extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t*
     if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
-    if (grid_size == 15) {
+    const DetWorkspace det = ctf_policy_det(device_id);
+    a.part = (det.ptr && (a.db2 || a.db1)) ? det.ptr : nullptr;
+    if (a.part && blocks * DGRAD_PART > det.floats) err = hipErrorOutOfMemory;
+    if (err != hipSuccess) {
+    } else if (grid_size == 15) {
         if (sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<15, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<15, false>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
     } else {
@@ -1045,7 +1090,10 @@ extern "C" int ctf_policy_front_dgrad(const uint16_t* d_act_dev, const uint16_t*
         if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<11, false>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
     }
     if (err == hipSuccess) err = hipGetLastError();
+    if (err == hipSuccess && a.part && a.db2) err = ctf_policy_det_reduce(a.part + 32 * 16 * 9, (int)blocks, DGRAD_PART, 32, a.db2, st);
+    if (err == hipSuccess && a.part && a.db1) err = ctf_policy_det_reduce(a.part + 32 * 16 * 9 + 32, (int)blocks, DGRAD_PART, 16, a.db1, st);
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err == hipErrorOutOfMemory) return pfail("deterministic mode: the registered workspace is too small for this launch (ctf_policy_set_deterministic)");
     if (err != hipSuccess) return pfail(hipGetErrorString(err));
     return 0;
 }
@@ -1068,6 +1116,7 @@ struct WgradArgs {
     const uint16_t* img;     // bf16 channels-last [S][GI*GI][16]: h1, or NULL when the image is built from codes
     const uint8_t* codes;    // uint8 [S][GI*GI] (conv1 only): the one-hot image's source
     float* dw;               // float [CO][16][9] += (the caller zeroes it)
+    float* part;             // deterministic mode: float [blocks][CO * 16 * 9], every block's own sum, else NULL (atomics)
     int64_t S;
 };
 // GO: side of the gradient image, GI = GO + 2: side of the activation image, CO: out channels (16 or 32)
@@ -1198,7 +1247,8 @@ __global__ void __launch_bounds__(128) k_policy_front_wgrad(WgradArgs a) {
         float v = 0.0f;
         for (int w = 0; w < wpb; w++) v += red[w * 9 * CO * 16 + e];
         const int t = e / (CO * 16), oi = e - t * (CO * 16);
-        atomicAdd(a.dw + (size_t)oi * 9 + t, v);  // [out][in][tap]
+        if (a.part) a.part[(size_t)blockIdx.x * (9 * CO * 16) + (size_t)oi * 9 + t] = v;
+        else atomicAdd(a.dw + (size_t)oi * 9 + t, v);  // [out][in][tap]
     }
 }
 
@@ -1227,8 +1277,13 @@ extern "C" int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h
         if (per_cu > 4) per_cu = 4;  // 8 waves per CU = 2 per SIMD
         int64_t blocks = (a.S + wpb - 1) / wpb;
         if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
+        WgradArgs b = a;
+        const DetWorkspace det = ctf_policy_det(device_id);
+        b.part = det.ptr;
+        if (err == hipSuccess && b.part && blocks * 9 * co * 16 > det.floats) err = hipErrorOutOfMemory;
         if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        if (err == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
+        if (err == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, b);
+        if (err == hipSuccess && b.part) err = ctf_policy_det_reduce(b.part, (int)blocks, 9 * co * 16, 9 * co * 16, b.dw, st);
     };
     WgradArgs a2, a1;
     a2.grad = dz2_dev; a2.img = h1_dev; a2.codes = nullptr; a2.dw = dw2_dev; a2.S = n_samples;
@@ -1242,6 +1297,7 @@ extern "C" int ctf_policy_front_wgrad(const uint16_t* dz2_dev, const uint16_t* h
     }
     if (err == hipSuccess) err = hipGetLastError();
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err == hipErrorOutOfMemory) return pfail("deterministic mode: the registered workspace is too small for this launch (ctf_policy_set_deterministic)");
     if (err != hipSuccess) return pfail(hipGetErrorString(err));
     return 0;
 }
@@ -1275,6 +1331,7 @@ extern "C" int ctf_policy_front_backward(const uint16_t* d_act_dev, const uint16
     if (dev_prev != device_id && hipSetDevice(device_id) != hipSuccess) return pfail("hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
+    const DetWorkspace det = ctf_policy_det(device_id);
     {   // the fused pass: four waves per block, one block per CU (the padded images are 25 KB per wave, the registers one wave per SIMD)
         const int wpb = 4;
         const int ra = G2 + 1 + ((G2 & 1) ? 0 : 1);
@@ -1284,13 +1341,19 @@ extern "C" int ctf_policy_front_backward(const uint16_t* d_act_dev, const uint16
         if (sh < red) sh = red;
         int64_t blocks = (n_samples + wpb - 1) / wpb;
         if (blocks > (int64_t)n_cus) blocks = n_cus;
-        if (grid_size == 15) {
+        a.part = det.ptr;
+        if (a.part && blocks * DGRAD_PART > det.floats) err = hipErrorOutOfMemory;
+        if (err != hipSuccess) {
+        } else if (grid_size == 15) {
             err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<15, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<15, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
         } else {
             err = hipFuncSetAttribute((const void*)k_policy_front_dgrad<11, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_dgrad<11, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a);
         }
+        if (err == hipSuccess && a.part) err = ctf_policy_det_reduce(a.part, (int)blocks, DGRAD_PART, 32 * 16 * 9, a.dw2, st);
+        if (err == hipSuccess && a.part && a.db2) err = ctf_policy_det_reduce(a.part + 32 * 16 * 9, (int)blocks, DGRAD_PART, 32, a.db2, st);
+        if (err == hipSuccess && a.part && a.db1) err = ctf_policy_det_reduce(a.part + 32 * 16 * 9 + 32, (int)blocks, DGRAD_PART, 16, a.db1, st);
     }
     {   // conv1's weight gradient (as in ctf_policy_front_wgrad)
         const int wpb = 2, go = G1, co = 16;
@@ -1305,6 +1368,8 @@ extern "C" int ctf_policy_front_backward(const uint16_t* d_act_dev, const uint16
         if (blocks > (int64_t)n_cus * per_cu) blocks = (int64_t)n_cus * per_cu;
         WgradArgs a1;
         a1.grad = dz1_dev; a1.img = nullptr; a1.codes = codes_dev; a1.dw = dw1_dev; a1.S = n_samples;
+        a1.part = det.ptr;
+        if (err == hipSuccess && a1.part && blocks * 9 * co * 16 > det.floats) err = hipErrorOutOfMemory;
         if (grid_size == 15) {
             if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_wgrad<13, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_wgrad<13, 16, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a1);
@@ -1312,9 +1377,11 @@ extern "C" int ctf_policy_front_backward(const uint16_t* d_act_dev, const uint16
             if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)k_policy_front_wgrad<9, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             if (err == hipSuccess) hipLaunchKernelGGL((k_policy_front_wgrad<9, 16, true>), dim3((unsigned)blocks), dim3(wpb * WAVE), sh, st, a1);
         }
+        if (err == hipSuccess && a1.part) err = ctf_policy_det_reduce(a1.part, (int)blocks, 9 * co * 16, 9 * co * 16, a1.dw, st);
     }
     if (err == hipSuccess) err = hipGetLastError();
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (err == hipErrorOutOfMemory) return pfail("deterministic mode: the registered workspace is too small for this launch (ctf_policy_set_deterministic)");
     if (err != hipSuccess) return pfail(hipGetErrorString(err));
     return 0;
 }

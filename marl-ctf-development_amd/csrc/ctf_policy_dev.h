@@ -279,6 +279,18 @@ __device__ __forceinline__ void head_stages_bcde(const HeadArgs& a, uint8_t* xs,
 }
 
 
+// Deterministic mode (ctf_policy_set_deterministic, include/ctf_policy.h): with a workspace registered for the device, the weight /
+// bias gradient kernels do not end in float atomics on the gradient (whose order of arrival differs from run to run) — every block
+// stores its partial sums in its own slice of the workspace and a second launch adds the slices IN BLOCK ORDER.
+struct DetWorkspace {
+    float* ptr;      // NULL: off (atomics)
+    int64_t floats;
+};
+__attribute__((visibility("hidden"))) DetWorkspace ctf_policy_det(int device_id);
+// dst[i] += sum over b = 0 .. n_blocks - 1 (in that order, four interleaved chains) of part[b * stride + i], i < elems
+__attribute__((visibility("hidden"))) hipError_t ctf_policy_det_reduce(const float* part, int n_blocks, int64_t stride, int elems, float* dst,
+                                                                      hipStream_t st);
+
 // host-side helpers defined in ctf_policy.hip
 __attribute__((visibility("hidden"))) int ctf_policy_fail(const char* msg);      // sets ctf_policy_last_error(), returns -1
 __attribute__((visibility("hidden"))) int ctf_policy_cus(int device_id);          // compute units of a device (cached), 0 on error

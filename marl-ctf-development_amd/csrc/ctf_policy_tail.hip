@@ -27,6 +27,8 @@ struct TailWgradArgs {
     float* db;            // float [N] +=, or NULL
     int64_t M;
     int32_t x_stride, dw_stride, k_base, n_slabs;  // n_slabs > 1 (fc1): block b works on column slab b % n_slabs, sample range b / n_slabs
+    float* part;          // deterministic mode: float [blocks][part_stride], every block's own tile [N][K] then its bias sums [N]; NULL: atomics
+    int64_t part_stride;
 };
 
 #define TAIL_CH 64     // samples per chunk (two K-steps of 32)
@@ -116,24 +118,51 @@ __global__ void __launch_bounds__(256) k_tail_wgrad(TailWgradArgs a) {
         __syncthreads();  // the next chunk overwrites the tiles
     }
     // D tile: lane holds rows (n) 4 (lane >> 4) + r of column (k) lane & 15
+    float* part = a.part ? a.part + (size_t)blockIdx.x * a.part_stride : nullptr;
 #pragma unroll
     for (int i = 0; i < WN; i++)
 #pragma unroll
         for (int j = 0; j < WK; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                atomicAdd(a.dw + (size_t)(16 * (n0 + i) + 4 * (lane >> 4) + r) * a.dw_stride + kcol + 16 * (k0 + j) + (lane & 15), acc[i][j][r]);
-    if (a.db) {  // a thread's eight columns: octet tid % PA; the block's partial sums meet in LDS, one atomic per column and block
-        float* red = (float*)tail_lds;
+            for (int r = 0; r < 4; r++) {
+                const int n = 16 * (n0 + i) + 4 * (lane >> 4) + r, k = 16 * (k0 + j) + (lane & 15);
+                if (part) part[n * K + k] = acc[i][j][r];
+                else atomicAdd(a.dw + (size_t)n * a.dw_stride + kcol + k, acc[i][j][r]);
+            }
+    if (a.db) {  // a thread's eight columns: octet tid % PA.  The block's 256 / PA partial sums per column meet in LDS and are added in
+                 // thread order (a fixed order: the block's bias sum does not depend on how its waves were scheduled)
+        float* red = (float*)tail_lds;  // [256][8]
         __syncthreads();
-        for (int q = tid; q < N; q += 256) red[q] = 0.0f;
-        __syncthreads();
-        const int oct = tid % PA;
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&red[oct * 8 + j], bsum[j]);
+        for (int j = 0; j < 8; j++) red[tid * 8 + j] = bsum[j];
         __syncthreads();
-        for (int q = tid; q < N; q += 256) atomicAdd(a.db + q, red[q]);
+        for (int q = tid; q < N; q += 256) {
+            float t = 0.0f;
+            for (int u = q >> 3; u < 256; u += PA) t += red[u * 8 + (q & 7)];
+            if (part) part[N * K + q] = t;
+            else atomicAdd(a.db + q, t);
+        }
     }
+}
+
+// deterministic mode: dw[n][k_base + slab * K + k] += the blocks' tiles of that slab, sample ranges in ascending order
+__global__ void __launch_bounds__(256) k_tail_det_reduce(const float* part, int64_t stride, int n_ranges, int n_slabs, int N, int K, float* dw,
+                                                         int dw_stride, int k_base) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_slabs * N * K) return;
+    const int slab = idx / (N * K), rem = idx - slab * (N * K), n = rem / K, k = rem - n * K;
+    const float* p = part + (size_t)slab * stride + rem;
+    const size_t step = (size_t)n_slabs * stride;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int r = 0;
+    for (; r + 3 < n_ranges; r += 4) {
+        s0 += p[(size_t)r * step];
+        s1 += p[(size_t)(r + 1) * step];
+        s2 += p[(size_t)(r + 2) * step];
+        s3 += p[(size_t)(r + 3) * step];
+    }
+    for (; r < n_ranges; r++) s0 += p[(size_t)r * step];
+    dw[(size_t)n * dw_stride + k_base + slab * K + k] += (s0 + s1) + (s2 + s3);
 }
 
 extern "C" int ctf_policy_linear_wgrad(const uint16_t* dy_dev, const uint16_t* x_dev, int64_t n_samples, int32_t n_out, int32_t n_in, float* dw_dev,
@@ -153,10 +182,21 @@ extern "C" int ctf_policy_linear_wgrad(const uint16_t* dy_dev, const uint16_t* x
     const int64_t n_chunks = (n_samples + TAIL_CH - 1) / TAIL_CH;
     hipStream_t st = (hipStream_t)stream;
     hipError_t err = hipSuccess;
+    const DetWorkspace det = ctf_policy_det(device_id);
+    bool too_small = false;
     auto launch = [&](auto kernel, int n, int k, int64_t blocks) {
         const size_t sh = (size_t)TAIL_CH * (n * 2 + TAIL_PAD) + (size_t)TAIL_CH * (k * 2 + TAIL_PAD);
+        a.part = det.ptr;
+        a.part_stride = (int64_t)n * k + n;
+        if (a.part && blocks * a.part_stride > det.floats) { too_small = true; return; }
         if (err == hipSuccess && sh > 48 * 1024) err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (err == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), sh, st, a);
+        if (err == hipSuccess && a.part) {  // the blocks' tiles -> dw (and db), in block order
+            const int ranges = (int)(blocks / a.n_slabs);
+            hipLaunchKernelGGL(k_tail_det_reduce, dim3((unsigned)((a.n_slabs * n * k + 255) / 256)), dim3(256), 0, st, (const float*)a.part, a.part_stride,
+                               ranges, a.n_slabs, n, k, a.dw, a.dw_stride, a.k_base);
+            if (a.db) err = ctf_policy_det_reduce(a.part + (size_t)n * k, (int)blocks, a.part_stride, n, a.db, st);
+        }
     };
     auto capped = [&](int per_cu) { return n_chunks < (int64_t)n_cus * per_cu ? n_chunks : (int64_t)n_cus * per_cu; };
     if (n_out == 128 && n_in == 256) launch(k_tail_wgrad<8, 16>, 128, 256, capped(2));       // fc2
@@ -178,6 +218,7 @@ extern "C" int ctf_policy_linear_wgrad(const uint16_t* dy_dev, const uint16_t* x
     } else err = hipErrorInvalidValue;
     if (err == hipSuccess) err = hipGetLastError();
     if (dev_prev != device_id) (void)hipSetDevice(dev_prev);
+    if (too_small) return ctf_policy_fail("deterministic mode: the registered workspace is too small for this launch (ctf_policy_set_deterministic)");
     if (err == hipErrorInvalidValue) return ctf_policy_fail("ctf_policy_linear_wgrad is built for (n_out, n_in) = (128, 256), (16, 128) and (256, a multiple of 64 without bias)");
     if (err != hipSuccess) return ctf_policy_fail(hipGetErrorString(err));
     return 0;

@@ -19,6 +19,8 @@ agent without ``trunk_codes`` (the reference's own ``Agent``) gets the codes exp
   step sums the gradients before ``clip_grad_norm_`` and Adam — so the N ranks' update is the single-process update on the union of
   their shards (tests/test_learner_dp_gloo.py: equal to 1e-6 in float32, 1e-10 in float64).
 """
+import contextlib
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -96,7 +98,10 @@ def broadcast_module(module, src=0, group=None):
 
 
 class PPOLearner:
-    def __init__(self, agent, n_channels, world=1, rank=0, group=None, order=None, sync_params=True, force_collective=False, **args):
+    DET_WORKSPACE_FLOATS = 24 << 20  # 96 MB: every launch of the 8_arena network on a 256-CU device (include/ctf_policy.h)
+
+    def __init__(self, agent, n_channels, world=1, rank=0, group=None, order=None, sync_params=True, force_collective=False,
+                 deterministic=None, **args):
         """agent: a module with the reference's ``get_action_and_value`` / ``get_value`` (policy.CtfPolicy,
         policy_native.CtfPolicyNative or the reference's own Agent).  n_channels: C of the observation (to expand codes).
 
@@ -107,8 +112,15 @@ class PPOLearner:
         reference's own (ppo.py:192; what tests/golden/learner_ref.npz pins); "device": ``torch.randperm`` on the learner's device,
         seeded per epoch with one integer drawn from ``np.random`` (rank 0's, broadcast) — identical on every rank without moving
         a permutation of the global batch between hosts, and no 0.1-0.2 s host shuffle per 4 M samples in front of every epoch.
-        Default: "numpy" alone, "device" in a job of several ranks."""
+        Default: "numpy" alone, "device" in a job of several ranks.
+        deterministic (default: the environment's CTF_DETERMINISTIC=1): the native network's weight / bias gradients are reduced in a
+        FIXED order — every block of the gradient kernels stores its partial sums, a second launch adds them in block order
+        (ctf_policy_set_deterministic) — instead of through float atomics: two identical updates are then bit-identical, as two runs
+        of the reference's update under the same seeds are (ppo.py:174-242).  Costs a 96 MB workspace and a few per cent of the
+        update (profiles/r05_deterministic_learner.md)."""
         self.agent, self.n_channels = agent, int(n_channels)
+        self.deterministic = (os.environ.get("CTF_DETERMINISTIC", "0") not in ("", "0")) if deterministic is None else bool(deterministic)
+        self._det_ws = None
         self.codes_direct = hasattr(agent, "trunk_codes")  # False: always expand (the reference's own Agent, or to compare the two paths)
         self.args = SimpleNamespace(**dict(DEFAULT_ARGS, **args))
         self.world, self.rank, self.group = int(world), int(rank), group
@@ -136,7 +148,9 @@ class PPOLearner:
         if self._flat is None or self._flat[1] != stamp:
             dt, dev = ps[0].dtype, ps[0].device
             if any(p.dtype != dt or p.device != dev for p in ps):
-                raise ValueError("the flat gradient buffer needs parameters of one dtype on one device")
+                if not self.dp:  # alone: nothing is all-reduced, the parameters keep gradients of their own
+                    return None
+                raise ValueError("the flat gradient buffer of a job of several ranks needs parameters of one dtype on one device")
             self._flat = (torch.zeros(sum(p.numel() for p in ps), dtype=dt, device=dev), stamp)
         flat, off = self._flat[0], 0
         for p in ps:
@@ -212,10 +226,12 @@ class PPOLearner:
         if dp:
             if not n_envs or local_size % int(n_envs):
                 raise ValueError("a job of several ranks needs n_envs, the env axis of this rank's [S, n_envs] rollout")
-            counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
-            counts[self.rank] = int(n_envs)
+            counts = torch.zeros((self.world, 2), dtype=torch.int64, device=dev)
+            counts[self.rank, 0], counts[self.rank, 1] = int(n_envs), local_size // int(n_envs)
             self._all_reduce(counts)
-            counts = counts.tolist()
+            counts, slots = counts[:, 0].tolist(), counts[:, 1].tolist()
+            if len(set(slots)) != 1:  # (a rank with another rollout length would index out of range or hang a later collective)
+                raise ValueError(f"every rank of the job must hold a rollout of the same number of slots; the ranks report {slots}")
             e_loc, e_tot, lo = int(n_envs), sum(counts), sum(counts[:self.rank])
             batch_size = (local_size // e_loc) * e_tot
         else:
@@ -226,81 +242,114 @@ class PPOLearner:
         flat_grads = self._flat_grads()
         v_loss = pg_loss = entropy_loss = approx_kl = None
         stats = None
-        for epoch in range(a.update_epochs):
-            inds_dev = self._epoch_order(batch_size, dev)  # the epoch's order (global), on the device once
-            if dp:
-                # this rank's share of every global minibatch, for the whole epoch at once (one host round trip per epoch): the samples
-                # whose env column is one of its own, in the order the permutation lists them
-                col = inds_dev % e_tot
-                mine = (col >= lo) & (col < lo + e_loc)
-                local_all = ((inds_dev // e_tot) * e_loc + (col - lo))[mine]
-                bounds = torch.tensor(starts + [batch_size], device=dev)
-                cum = torch.cat([mine.new_zeros(1, dtype=torch.int64), mine.cumsum(0)])
-                offs = cum[bounds].tolist()
-                # the advantage statistics of every global minibatch: (sum, sum of squares, count) of the local shares, ONE all-reduce
-                adv_stats = torch.zeros((len(starts), 3), dtype=torch.float64, device=dev)
-                for k in range(len(starts)):
-                    x = b_advantages[local_all[offs[k]:offs[k + 1]]].double()
-                    adv_stats[k, 0], adv_stats[k, 1], adv_stats[k, 2] = x.sum(), (x * x).sum(), x.numel()
-                self._all_reduce(adv_stats)
-            for k, start in enumerate(starts):
+        with self._deterministic_scope(dev):
+            for epoch in range(a.update_epochs):
+                inds_dev = self._epoch_order(batch_size, dev)  # the epoch's order (global), on the device once
                 if dp:
-                    mb_all = local_all[offs[k]:offs[k + 1]]
-                    n_mb = min(start + minibatch_size, batch_size) - start  # of the GLOBAL minibatch: every mean below is over it
-                    mb_adv_all = b_advantages[mb_all]
-                    if a.norm_adv:  # ppo.py:206-208 over the global minibatch: mean, and torch.std's unbiased estimator
-                        tot, sq, cnt = adv_stats[k, 0], adv_stats[k, 1], adv_stats[k, 2]
-                        mean = tot / cnt
-                        std = ((sq - cnt * mean * mean).clamp(min=0) / (cnt - 1)).sqrt()
-                        mb_adv_all = ((mb_adv_all.double() - mean) / (std + 1e-8)).to(mb_adv_all.dtype)
-                else:
-                    mb_all = inds_dev[start:start + minibatch_size]
-                    n_mb = mb_all.numel()
-                    mb_adv_all = b_advantages[mb_all]
-                    if a.norm_adv:
-                        mb_adv_all = (mb_adv_all - mb_adv_all.mean()) / (mb_adv_all.std() + 1e-8)
-                flat_grads.zero_()
-                n_here = mb_all.numel()
-                piece = max(n_here, 1) if not micro_batch else int(micro_batch)
-                sums = torch.zeros(5, dtype=torch.float64, device=dev)  # pg, v, entropy, kl, clip: summed on the device
-                for lo_p in range(0, n_here, piece):
-                    mb, mb_advantages = mb_all[lo_p:lo_p + piece], mb_adv_all[lo_p:lo_p + piece]
-                    _, newlogprob, entropy, newvalue = agent.get_action_and_value(self._planes(b_grids[mb]), b_metadata_states[mb].to(torch.float32),
-                                                                                  b_use_action_mask[mb], b_actions[mb].long())
-                    logratio = newlogprob - b_logprobs[mb]
-                    ratio = logratio.exp()
-                    with torch.no_grad():
-                        kl_sum = ((ratio - 1) - logratio).sum()
-                        clip_sum = ((ratio - 1.0).abs() > a.clip_coef).float().sum()
-                    pg_loss1 = -mb_advantages * ratio
-                    pg_loss2 = -mb_advantages * torch.clamp(ratio, 1 - a.clip_coef, 1 + a.clip_coef)
-                    pg_sum = torch.max(pg_loss1, pg_loss2).sum()
-                    newvalue = newvalue.view(-1)
-                    if a.clip_vloss:
-                        v_loss_unclipped = (newvalue - b_returns[mb]) ** 2
-                        v_clipped = b_values[mb] + torch.clamp(newvalue - b_values[mb], -a.clip_coef, a.clip_coef)
-                        v_loss_clipped = (v_clipped - b_returns[mb]) ** 2
-                        v_sum = 0.5 * torch.max(v_loss_unclipped, v_loss_clipped).sum()
+                    # this rank's share of every global minibatch, for the whole epoch at once (one host round trip per epoch): the samples
+                    # whose env column is one of its own, in the order the permutation lists them
+                    col = inds_dev % e_tot
+                    mine = (col >= lo) & (col < lo + e_loc)
+                    local_all = ((inds_dev // e_tot) * e_loc + (col - lo))[mine]
+                    bounds = torch.tensor(starts + [batch_size], device=dev)
+                    cum = torch.cat([mine.new_zeros(1, dtype=torch.int64), mine.cumsum(0)])
+                    offs = cum[bounds].tolist()
+                    # the advantage statistics of every global minibatch: (sum, sum of squares, count) of the local shares, ONE all-reduce
+                    adv_stats = torch.zeros((len(starts), 3), dtype=torch.float64, device=dev)
+                    for k in range(len(starts)):
+                        x = b_advantages[local_all[offs[k]:offs[k + 1]]].double()
+                        adv_stats[k, 0], adv_stats[k, 1], adv_stats[k, 2] = x.sum(), (x * x).sum(), x.numel()
+                    self._all_reduce(adv_stats)
+                for k, start in enumerate(starts):
+                    if dp:
+                        mb_all = local_all[offs[k]:offs[k + 1]]
+                        n_mb = min(start + minibatch_size, batch_size) - start  # of the GLOBAL minibatch: every mean below is over it
+                        mb_adv_all = b_advantages[mb_all]
+                        if a.norm_adv:  # ppo.py:206-208 over the global minibatch: mean, and torch.std's unbiased estimator
+                            tot, sq, cnt = adv_stats[k, 0], adv_stats[k, 1], adv_stats[k, 2]
+                            mean = tot / cnt
+                            std = ((sq - cnt * mean * mean).clamp(min=0) / (cnt - 1)).sqrt()
+                            mb_adv_all = ((mb_adv_all.double() - mean) / (std + 1e-8)).to(mb_adv_all.dtype)
                     else:
-                        v_sum = 0.5 * ((newvalue - b_returns[mb]) ** 2).sum()
-                    ent_sum = entropy.sum()
-                    # loss = pg_loss - ent_coef * entropy_loss + v_loss * vf_coef with every term a mean over the minibatch
-                    ((pg_sum - a.ent_coef * ent_sum + v_sum * a.vf_coef) / n_mb).backward()
-                    sums += torch.stack([pg_sum.detach(), v_sum.detach(), ent_sum.detach(), kl_sum, clip_sum]).double()
-                if dp:  # ONE flat all-reduce of the gradients per optimiser step (+ the five loss sums, so that every rank reports the
-                    self._all_reduce(flat_grads)  # global minibatch's numbers and takes the same early-stop decision)
-                    self._all_reduce(sums)
-                stats = sums / n_mb  # stays on the device: the host reads the numbers once per epoch (or per minibatch for `progress`)
-                nn.utils.clip_grad_norm_(agent.parameters(), a.max_grad_norm)
-                self.optimizer.step()
-                if progress is not None:
-                    pg_loss, v_loss, entropy_loss, approx_kl, _ = stats.tolist()
-                    progress(f"epoch {epoch} minibatch at {start}: v {v_loss:.4g} pg {pg_loss:.4g} entropy {entropy_loss:.4g}")
-            if stats is not None:
-                pg_loss, v_loss, entropy_loss, approx_kl, _ = stats.tolist()  # of the epoch's last minibatch, as the reference keeps them
-            if a.target_kl is not None and approx_kl > a.target_kl:
-                break
-        return v_loss, pg_loss, entropy_loss
+                        mb_all = inds_dev[start:start + minibatch_size]
+                        n_mb = mb_all.numel()
+                        mb_adv_all = b_advantages[mb_all]
+                        if a.norm_adv and self.deterministic:
+                            # the N-rank formula (float64 sums) alone too: a one-rank job and the single process are then the SAME
+                            # computation, bit for bit (within 1 ulp of float32 of torch's mean / std below)
+                            x = mb_adv_all.double()
+                            cnt = x.numel()
+                            mean = x.sum() / cnt
+                            std = (((x * x).sum() - cnt * mean * mean).clamp(min=0) / (cnt - 1)).sqrt()
+                            mb_adv_all = ((x - mean) / (std + 1e-8)).to(mb_adv_all.dtype)
+                        elif a.norm_adv:
+                            mb_adv_all = (mb_adv_all - mb_adv_all.mean()) / (mb_adv_all.std() + 1e-8)
+                    if flat_grads is not None:
+                        flat_grads.zero_()
+                    else:
+                        self.optimizer.zero_grad(set_to_none=True)
+                    n_here = mb_all.numel()
+                    piece = max(n_here, 1) if not micro_batch else int(micro_batch)
+                    sums = torch.zeros(5, dtype=torch.float64, device=dev)  # pg, v, entropy, kl, clip: summed on the device
+                    for lo_p in range(0, n_here, piece):
+                        mb, mb_advantages = mb_all[lo_p:lo_p + piece], mb_adv_all[lo_p:lo_p + piece]
+                        _, newlogprob, entropy, newvalue = agent.get_action_and_value(self._planes(b_grids[mb]), b_metadata_states[mb].to(torch.float32),
+                                                                                      b_use_action_mask[mb], b_actions[mb].long())
+                        logratio = newlogprob - b_logprobs[mb]
+                        ratio = logratio.exp()
+                        with torch.no_grad():
+                            kl_sum = ((ratio - 1) - logratio).sum()
+                            clip_sum = ((ratio - 1.0).abs() > a.clip_coef).float().sum()
+                        pg_loss1 = -mb_advantages * ratio
+                        pg_loss2 = -mb_advantages * torch.clamp(ratio, 1 - a.clip_coef, 1 + a.clip_coef)
+                        pg_sum = torch.max(pg_loss1, pg_loss2).sum()
+                        newvalue = newvalue.view(-1)
+                        if a.clip_vloss:
+                            v_loss_unclipped = (newvalue - b_returns[mb]) ** 2
+                            v_clipped = b_values[mb] + torch.clamp(newvalue - b_values[mb], -a.clip_coef, a.clip_coef)
+                            v_loss_clipped = (v_clipped - b_returns[mb]) ** 2
+                            v_sum = 0.5 * torch.max(v_loss_unclipped, v_loss_clipped).sum()
+                        else:
+                            v_sum = 0.5 * ((newvalue - b_returns[mb]) ** 2).sum()
+                        ent_sum = entropy.sum()
+                        # loss = pg_loss - ent_coef * entropy_loss + v_loss * vf_coef with every term a mean over the minibatch
+                        ((pg_sum - a.ent_coef * ent_sum + v_sum * a.vf_coef) / n_mb).backward()
+                        sums += torch.stack([pg_sum.detach(), v_sum.detach(), ent_sum.detach(), kl_sum, clip_sum]).double()
+                    if dp:  # ONE flat all-reduce of the gradients per optimiser step (+ the five loss sums, so that every rank reports the
+                        self._all_reduce(flat_grads)  # global minibatch's numbers and takes the same early-stop decision)
+                        self._all_reduce(sums)
+                    stats = sums / n_mb  # stays on the device: the host reads the numbers once per epoch (or per minibatch for `progress`)
+                    nn.utils.clip_grad_norm_(agent.parameters(), a.max_grad_norm)
+                    self.optimizer.step()
+                    if progress is not None:
+                        pg_loss, v_loss, entropy_loss, approx_kl, _ = stats.tolist()
+                        progress(f"epoch {epoch} minibatch at {start}: v {v_loss:.4g} pg {pg_loss:.4g} entropy {entropy_loss:.4g}")
+                if stats is not None:
+                    pg_loss, v_loss, entropy_loss, approx_kl, _ = stats.tolist()  # of the epoch's last minibatch, as the reference keeps them
+                if a.target_kl is not None and approx_kl > a.target_kl:
+                    break
+            return v_loss, pg_loss, entropy_loss
+
+    @contextlib.contextmanager
+    def _deterministic_scope(self, dev):
+        """Registers the fixed-order reduction workspace for the update's duration (deterministic=True on a native network on a GPU)."""
+        lib = None
+        if self.deterministic and dev.type == "cuda" and hasattr(self.agent, "native_training"):
+            if self._det_ws is None or self._det_ws.device != dev:
+                self._det_ws = torch.empty(self.DET_WORKSPACE_FLOATS, dtype=torch.float32, device=dev)
+            try:
+                from . import _abi
+            except ImportError:  # pragma: no cover
+                import _abi
+            lib = _abi.load_library()
+            if lib.ctf_policy_set_deterministic(dev.index, self._det_ws.data_ptr(), self._det_ws.numel()) != 0:
+                raise _abi.CtfLibraryError("ctf_policy_set_deterministic: " + (lib.ctf_policy_last_error() or b"").decode())
+        try:
+            yield
+        finally:
+            if lib is not None:
+                torch.cuda.current_stream(dev).synchronize()  # (the update's last launches still write into the workspace)
+                lib.ctf_policy_set_deterministic(dev.index, None, 0)
 
     def update(self, rollout, micro_batch=None, progress=None):
         """GAE + PPO update on one collected rollout -> (v_loss, pg_loss, entropy_loss).  The batch is the rollout flattened

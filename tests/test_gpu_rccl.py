@@ -104,8 +104,9 @@ def test_data_parallel_ppo_update_over_rccl_with_one_rank():
     the plain single-process update with the same order source:
     * on the float32 stock network (deterministic kernels) to float32 round-off — the normalisation's statistics come from float64
       sums on the N-rank path, nothing else differs;
-    * on the native network (bf16 MFMA kernels, float atomics in the weight gradients: not run-to-run stable, and Adam turns a
-      gradient near zero into a full step of either sign) no further than two single-process runs are from each other."""
+    * on the native network in deterministic mode (fixed-order gradient reductions) likewise, and two runs are bit-identical;
+    * on the native network in its default mode (bf16 MFMA kernels, float atomics in the weight gradients: not run-to-run stable, and
+      Adam turns a gradient near zero into a full step of either sign) no further than two single-process runs are from each other."""
     import copy
     import os, sys
 
@@ -150,7 +151,16 @@ def test_data_parallel_ppo_update_over_rccl_with_one_rank():
         assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
         assert np.allclose(l_dp, l_sp, rtol=1e-5, atol=1e-6), (l_dp, l_sp)
 
+        # deterministic mode (fixed-order gradient reductions, tests/test_gpu_deterministic.py): run-to-run identical, and the single
+        # process takes its advantage statistics from the same float64 sums as the N-rank path — a one-rank job IS the single process
         base = fill_(pn.CtfPolicyNative(9, c, g, m)).to(dev)
+        a, l_dp = updated(base, world=1, rank=0, force_collective=True, deterministic=True)
+        a2, l_dp2 = updated(base, world=1, rank=0, force_collective=True, deterministic=True)
+        b, l_sp = updated(base, order="device", deterministic=True)
+        assert torch.equal(a, a2) and l_dp == l_dp2
+        print("deterministic dp vs sp: max", float((a - b).abs().max()), "mean", float((a - b).abs().mean()))
+        assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
+
         a, l_dp = updated(base, world=1, rank=0, force_collective=True)
         b, l_sp = updated(base, order="device")
         b2, l_sp2 = updated(base, order="device")
