@@ -31,6 +31,18 @@ from .policy import CtfPolicy
 _TWO_LOG2E = 2.0 / math.log(2.0)
 
 
+def _has_mm_out_dtype():
+    """torch.mm / torch.bmm with ``out_dtype=`` (bf16 operands, float32 result: torch >= 2.8).  Without it the view GEMM of the factored
+    front runs as the native kernel (ctf_policy_view_gemm: bit-identical, tested) and fc1's weight gradient as one bf16 GEMM."""
+    try:
+        return all("dtype" in op.overloads() and "dtype_out" in op.overloads() for op in (torch.ops.aten.mm, torch.ops.aten.bmm))
+    except Exception:  # pragma: no cover - a torch whose op registry looks different: take the conservative path
+        return False
+
+
+MM_OUT_DTYPE = _has_mm_out_dtype()
+
+
 def conv_fragments(conv1_w, conv1_b, conv2_w, conv2_b):
     """float32 conv parameters -> the kernel's operands (include/ctf_policy.h): bf16 MFMA A-fragments of both
     convolutions and float32 biases, all scaled by 2 log2(e) (the kernel's tanh works on base-2 exponents)."""
@@ -269,7 +281,7 @@ class _Fc1Linear(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             m = int(dy.shape[0])
-            if m % _Fc1Linear.WGRAD_RANGES == 0 and m // _Fc1Linear.WGRAD_RANGES >= 2048:
+            if MM_OUT_DTYPE and m % _Fc1Linear.WGRAD_RANGES == 0 and m // _Fc1Linear.WGRAD_RANGES >= 2048:
                 # dW = dy^T act as 32 partial products over sample ranges (float32 out) + their sum: the library runs the ONE GEMM (a
                 # 256 x Kp output, K = the batch) as split-K with a fix-up pass at half the rate — 1.10 ms against 0.65 per 262 144
                 # samples, 4.11 against 2.50 per 1 048 576 (tools/fc1_wgrad_probe.py); float32 partials instead of one bf16 rounding
@@ -293,6 +305,7 @@ class _Fc1Linear(torch.autograd.Function):
 
 
 class CtfPolicyNative(CtfPolicy):
+    tune_placement = True   # the factored front's view buffer: a few candidate allocations timed with the real work on first use (_fact_run)
     native_training = True  # trunk_codes with gradients: the native front as the forward (False: the stock modules, as on CPU)
     native_wgrad = True     # ... and the two convolution weight gradients by ctf_policy_front_wgrad (False: the library's kernels)
     fused_head = False      # the network's tail fused behind the patch product (ctf_policy_fc1_patch_head): bit-identical, and measured
@@ -524,7 +537,7 @@ class CtfPolicyNative(CtfPolicy):
         def front_and_gemm(view):
             ok(lib.ctf_policy_features_fact(ptr(codes), ptr(meta), ptr(self_cells), E, N, G, M, sel_arr, A, ptr(p["f1"]), ptr(p["b1"]), ptr(p["f2"]),
                                             ptr(p["b2"]), ptr(b["slot_of"]), ptr(view), ptr(b["prow"]), dev.index, stream), "ctf_policy_features_fact")
-            if self.native_view_gemm:  # float32 out either way: the patch product is added before the one rounding
+            if self.native_view_gemm or not MM_OUT_DTYPE:  # float32 out either way: the patch product is added before the one rounding
                 ok(lib.ctf_policy_view_gemm(ptr(view), ptr(p["fc1_view_w"]), E, b["kv"], ptr(b["yview"]), dev.index, stream), "ctf_policy_view_gemm")
             elif E % 4 == 0:
                 # the library's fastest form of this product (tools/view_gemm_forms_probe.py, 65 536 x 4 096: 0.154 ms; the plain
@@ -539,7 +552,10 @@ class CtfPolicyNative(CtfPolicy):
             # of the view matrix ~25 % (0.22 against 0.16 ms for the GEMM of a 65 536-env step).  Once per buffer: candidates are timed
             # with the real work, a loser goes back to the driver at once (two held at most), until both kinds were seen or 8 tries.
             b["placed"] = True
-            if b["view"].numel() * 2 > (256 << 20):
+            import os
+
+            # (several ranks on ONE device — CTF_BENCH_ONE_DEVICE, a rehearsal — would time each other: no search there)
+            if b["view"].numel() * 2 > (256 << 20) and self.tune_placement and not os.environ.get("CTF_BENCH_ONE_DEVICE"):
                 def probe(view):
                     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     front_and_gemm(view)
@@ -557,7 +573,10 @@ class CtfPolicyNative(CtfPolicy):
                         break
                     times.append(probe(cand))
                     if times[-1] < min(times[:-1]):
-                        b["view"] = cand
+                        b["view"], cand = cand, b["view"]
+                    # the loser goes back to the DRIVER: the next candidate must be a fresh allocation, not this block again.  (empty_cache
+                    # returns the allocator's FREE blocks only — no live tensor of a co-resident learner is touched; it re-allocates what it
+                    # had cached.  tune_placement = False, or prepare_placement() from a warm-up, keeps this out of a timed collect().)
                     del cand
                     torch.cuda.empty_cache()
                 self.placement_probe_ms = times

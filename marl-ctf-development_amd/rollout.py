@@ -180,6 +180,7 @@ class BatchedRolloutCollector:
         torch, vec, A = self.torch, self.vec, self.A
         E, N = vec.n_envs, vec.N_AGENTS
         codes, meta = vec.observe_codes()  # default reversal: team(i) == 1
+        assert codes.dtype == torch.uint8 and meta.dtype == torch.float16 and codes.is_contiguous() and meta.is_contiguous()
         one_team = lambda agents: len({vec.AGENT_TEAMS[i] for i in agents}) == 1
         if self._store_args is None:
             lib = _abi.load_library()
@@ -233,7 +234,11 @@ class BatchedRolloutCollector:
             vec.reset()  # ppo.py:57
         self.dones.zero_()
         done = None
-        fast = bool(use_codes and self.native_store and vec.device.type == "cuda" and not self.overlap_teams)
+        # the one-launch bookkeeping (ctf_rollout_store_step) takes raw pointers: contiguous uint8 codes / float16 metadata, N <= 16 agents,
+        # at most 8 per list, metadata rows of <= 64 elements; any other configuration keeps the tensor-expression path below
+        fast = bool(use_codes and self.native_store and vec.device.type == "cuda" and not self.overlap_teams
+                    and vec.meta.dtype == torch.float16 and vec.meta.is_contiguous() and vec.codes.dtype == torch.uint8
+                    and vec.codes.is_contiguous() and vec.N_AGENTS <= 16 and A <= 8 and len(self.others) <= 8 and vec.META_LEN <= 64)
         if fast:  # the masking decision of a trained slot is a constant of the collector: written once, not per step
             self.use_action_mask.view(self.T, A, E)[:] = self.mask_flag.index_select(0, self.trained_idx)[None, :, None]
         with torch.no_grad():

@@ -87,7 +87,11 @@ def emulate_fc1(net, yview, rows, cells_of_row, g):
 
 @pytest.mark.parametrize("g,c,n,e,sel", [(15, 14, 8, 300, [0, 1, 2, 3]), (15, 14, 8, 77, [4, 5, 6, 7]), (11, 8, 4, 500, [0, 1]), (11, 8, 4, 65, [3]),
                                          (15, 14, 6, 129, [5, 1, 3])])
-def test_factored_fc1_matches_its_float64_emulation_to_one_bf16_ulp(g, c, n, e, sel):
+def test_factored_fc1_matches_its_float64_emulation(g, c, n, e, sel):
+    """Two separate bounds on every fc1 output against the float64 sum of the kernels' own operands: ONE bf16 spacing wherever the output
+    is not a near-cancellation (|want| >= 2^-6, where a spacing is >= 6e-5), and an ABSOLUTE 1e-4 (the float32 accumulation error of
+    ~900 products of magnitude up to ~16) plus one spacing where the terms cancel to ~0 — where "one ulp" alone would claim more than
+    float32 accumulation can give."""
     rng = np.random.default_rng(1000 * g + e)
     m = 2 * n + 6
     p2 = (g - 4) ** 2
@@ -115,8 +119,10 @@ def test_factored_fc1_matches_its_float64_emulation_to_one_bf16_ulp(g, c, n, e, 
     yview = b["yview"].double().cpu().repeat(len(sel), 1)
     want = emulate_fc1(net, yview, rows, cells_of_row, g)
     diff = (y1 - want).abs()
-    # (+ 1e-4: the float32 accumulation of ~900 products of magnitude up to ~16, which matters only where the terms cancel to ~0)
-    assert bool((diff <= ulp_bf16(want) * (1 + 1e-9) + 1e-4).all()), float((diff / ulp_bf16(want)).max())
+    big = want.abs() >= 2.0 ** -6
+    assert float(big.double().mean()) > 0.9                                                  # the ulp bound is the one that binds almost everywhere
+    assert bool((diff[big] <= ulp_bf16(want[big]) * (1 + 1e-9)).all()), float((diff[big] / ulp_bf16(want[big])).max())         # ONE spacing, nothing added
+    assert bool((diff[~big] <= ulp_bf16(want[~big]) * (1 + 1e-9) + 1e-4).all()), float(diff[~big].max())                      # near-cancellations: absolute
     # ... the view product itself against the float64 product of the same bf16 operands (float32 accumulation in the library)
     w = bf16(net.fc1.weight.detach().cpu().double() * S)[:, :32 * p2]
     yv = torch.zeros((e, 32 * p2), dtype=torch.float64)

@@ -6,10 +6,11 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 CS=marl-ctf-development_amd/csrc
 mkdir -p gpurun_out/ablate
+SRCS=$(make -s -C $CS print-srcs | sed "s#[^ ]*#$CS/&#g")  # the shipped library's own source list (csrc/Makefile)
 i=0
 for flags in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off $flags -shared \
-      -o gpurun_out/ablate/lib$i.so $CS/ctf_abi.hip $CS/ctf_kernels.hip $CS/ctf_policy.hip $CS/ctf_policy_fact.hip || exit 1
+      -o gpurun_out/ablate/lib$i.so $SRCS || exit 1
   i=$((i+1))
 done
 for round in 1 2; do

@@ -6,11 +6,12 @@ VARIANTS=${1:-"0 1 2 4 8"}
 ENVS=${2:-65536}
 SRC=marl-ctf-development_amd/csrc
 mkdir -p tools/_ab gpurun_out/ablate_policy
+SRCS=$(make -s -C $SRC print-srcs | sed "s#[^ ]*#$SRC/&#g")  # the shipped library's own source list (csrc/Makefile)
 for v in $VARIANTS; do
   so=tools/_ab/libctf_hip_pol$v.so
   if [ ! -f $so ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -DPOL_ABLATE=$v ${EXTRA_DEFS:-} \
-      -shared -o $so $SRC/ctf_abi.hip $SRC/ctf_kernels.hip $SRC/ctf_policy.hip || exit 1
+      -shared -o $so $SRCS || exit 1
   fi
 done
 if [ "${BUILD_ONLY:-0}" = "1" ]; then exit 0; fi
