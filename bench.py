@@ -494,6 +494,9 @@ def main():
                     help="also all-gather the compact rollout tensors (rewards, done) over RCCL, once per 16-step chunk, for a "
                          "centralised learner; off by default: env shards are independent and a data-parallel learner needs no exchange")
     ap.add_argument("--run", type=int, default=1, help="seed family: env seeds are 1_000_003*run + global env index")
+    ap.add_argument("--env-offset", type=int, default=0,
+                    help="global index of the job's first env (rank r owns [offset + r * E, offset + (r + 1) * E)): e.g. 98304 with "
+                         "--envs-per-gpu 32768 is the shard of rank 3 of 8 of configs[3]")
     ap.add_argument("--windows", type=int, default=5, help="back-to-back timed windows of --steps steps each; the line reports the median one")
     ap.add_argument("--configs3-envs", type=int, default=262144,
                     help="GLOBAL env count of the N>1 secondary (BASELINE.json configs[3]: 262 144 envs over the N GPUs)")
@@ -564,7 +567,7 @@ def main():
                              env_lo=env_lo)
         return reduce_windows(sh, r, device, world, use_dist)
 
-    r = measure(args.workload, E, K, use_gather=exchange, extras=(rank == 0))
+    r = measure(args.workload, E, K, env_lo=args.env_offset + rank * E, use_gather=exchange, extras=(rank == 0))
     elapsed = r["elapsed"]
     ranks_seen, per_rank_ms = sh.gather_rank_times(rank, r["my_ms"], world if use_dist else 1)
     # a multi-GPU line must verify itself: every rank of the job reported a time, exactly once
@@ -603,6 +606,7 @@ def main():
                                else "all envs in lock-step from episode step 0"),
                 "envs_per_gpu": E,
                 "global_envs": n_gpus * E,
+                "first_global_env": args.env_offset,
                 "metrics_counters": not args.no_metrics,
                 "ranks_share_one_device": bool(os.environ.get("CTF_BENCH_ONE_DEVICE")),
                 "rollout_exchange": ("RCCL all-gather of rewards+done per 16-step chunk, async" if exchange else

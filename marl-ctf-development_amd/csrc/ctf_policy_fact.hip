@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(256) k_fact_assign(BucketArgs a) {
 // Profiling-only phase trace (tools/trace_fact.py builds with -DPOL_TRACE=1): wave 0 of block 0 records s_memtime at the phase
 // boundaries of its first 64 envs.
 // Profiling-only ablations (never defined in the shipped build): bit0 no patch-row / view stores, bit1 patch row = the patched values
-// (no subtraction), bit2 conv2 patch operands always from the shared h1 (no address select), bit3 no conv2 patches at all
+// (no subtraction), bit2 conv2 patch operands always from the shared h1 (no address select), bit3 no conv2 patches at all,
+// bit4 no h0 rebuild and no shared conv1 (h1 keeps whatever LDS held: the upper bound of ANY cheaper conv1, round 5), bit5 no conv1 patches
 #ifndef FACT_ABLATE
 #define FACT_ABLATE 0
 #endif
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             slotw[k] = pol_async_dword((const uint32_t*)fa.slot_of + (size_t)kk * a.n_envs + e);
         }
         // ---- 1. h0 <- the shared planes (own-position bits stripped), from scratch: the previous env's h2s lies over it
-        {
+        if (!(FACT_ABLATE & 16)) {
             const u32x4_t z = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int q = 0; q < (GG * 2 + WAVE - 1) / WAVE; q++)
@@ -286,14 +287,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         for (int q = 0; q < NP; q++) {
             const int c = lane + WAVE * q;
             const uint32_t n = cur.b[q] & 0x7Fu;
-            if (c < GG && n) *(uint16_t*)(h0 + c * 16 + (n >> 3) * H0A + (n & 7u) * 2) = 0x3F80;
+            if (!(FACT_ABLATE & 16) && c < GG && n) *(uint16_t*)(h0 + c * 16 + (n >> 3) * H0A + (n & 7u) * 2) = 0x3F80;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         FACT_STAMP(1);
 
         // ---- 2. shared conv1 + tanh -> h1 (two tiles in flight)
-        constexpr int T1 = (P1 + 15) >> 4;
+        constexpr int T1 = (FACT_ABLATE & 16) ? 0 : ((P1 + 15) >> 4);
         int x1 = x1_0, cell1 = y1_0 * G + x1_0;
         int t = 0;
 #pragma unroll 1
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
             syv[k] = sc / G;
             sxv[k] = sc - syv[k] * G;
         }
-        {
+        if (!(FACT_ABLATE & 32)) {
             f32x4_t acc[4];
             const uint8_t* base[4];
             int own_tap[4];

@@ -72,7 +72,7 @@ def main():
                 f"(BENCH_ARGS={os.environ.get('PROFILE_BENCH_ARGS', 'see the script')}); passes found: "
                 + ", ".join(p for p in ("trace", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3") if os.path.isdir(os.path.join(src, p)))
                 + ".  kernel_stats averages run over ALL launches of the process (stagger phase, warm-up and secondaries included); the bench line's "
-                  "kernels_ms are HIP events around a sample of the timed region's launches.\n")
+                  "kernels_ms are HIP events around the two launches of 12 steps run AFTER the timed windows, net of an empty event pair.\n")
     out = {}
     for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
         path = one(os.path.join(src, p, "**", "*_counter_collection.csv"))
