@@ -933,13 +933,13 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
 // the chip then writes a compact window that moves linearly through the buffer and a wave issues few stores.  On MI355X a
 // wave that issues 1 / 4 / 8 / 25 store instructions in a row sustains 6.9 / 5.9 / 5.7 / 5.5 TB/s chip-wide, and the long
 // per-wave streams of k_observe lose another 15 % on the "slow" kind of allocation (on some boxes: every allocation) while
-// one-shot tiles do not (tools/store_bw8.hip, profiles/r02_store_bw8_tiles.txt).  The price: the cell scan is repeated by
+// one-shot tiles do not (profiles/r02_store_bw8_tiles.txt).  The price: the cell scan is repeated by
 // every tile of an env (3.1 tiles per arena env) for the views the tile holds, and every wave pays the prologue — so both are
 // kept lean: envs come in groups whose blocks fill a whole number of tiles (no 64-bit division), a cell's flipped index and
 // its channel code for either viewing team are worked out once per grid dword, a view costs ~7 instructions per cell, and
 // the metadata LUT comes from a table the host built.
 // The 1-D grid is walked XCD-contiguously (block b -> logical block (b % 8) * (blocks / 8) + b / 8): each of the 8 XCDs writes
-// its own eighth of the buffer front to back, 0.306 -> 0.259 ms on the arena (tools/store_bw9.hip for the bare pattern).
+// its own eighth of the buffer front to back, 0.306 -> 0.259 ms on the arena (profiles/r02_store_bw9_xcd.txt for the bare pattern).
 // Metadata rows: written by the wave whose tile holds an env's first byte.
 // Used when an env's block is a multiple of 16 bytes and >= one tile and the buffer is 16-byte aligned (ctf_launch_observe).
 #define OBS_TILE CTF_OBS_TILE
@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(256) k_observe_tiles(DevCfg cfg, DevPtrs p, ui
     // ---- which tile of which group of envs (uniform, 32-bit)
     // The launch is 1-D and consecutive workgroups go to consecutive XCDs (8 of them).  Block b therefore takes logical
     // block (b % 8) * (blocks / 8) + b / 8: every XCD writes ITS OWN contiguous eighth of the buffer front to back instead of
-    // every XCD touching every page — a constant 8 KiB-tile fill measures 6.2 instead of 5.6 TB/s that way (tools/store_bw9.hip).
+    // every XCD touching every page — a constant 8 KiB-tile fill measures 6.2 instead of 5.6 TB/s that way (profiles/r02_store_bw9_xcd.txt).
     const uint32_t b = blockIdx.x;
     const uint32_t lb = xcd_map ? (b & 7u) * ((uint32_t)cfg.tile_nb >> 3) + (b >> 3) : b;
     const uint32_t grp = fdiv(lb, cfg.div_tile_bx);

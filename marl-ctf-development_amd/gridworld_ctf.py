@@ -68,7 +68,7 @@ class VecGridworldCtf:
         """tune_placement: pick the observation buffer among a few candidate allocations by timing the render into each
         (default: on for batches whose observation block exceeds 256 MiB).  On MI355X about half of all large hipMalloc
         allocations stream 20 % slower than the others (6.5 vs 5.3 TB/s for a bare store stream into the very same
-        virtual address range after a free / re-allocate: it is the physical backing, tools/alloc_probe.hip)."""
+        virtual address range after a free / re-allocate: it is the physical backing, profiles/r02_alloc_probe*.txt)."""
         torch = _torch()
         self._lib = _lib or _abi.load_library()  # _lib: a side-by-side build, profiling only (tools/ab_inproc.py)
         if rng_mode not in ("mt19937", "counter"):
