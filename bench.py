@@ -203,7 +203,7 @@ def cpu_baseline(pkg, kwargs, budget_s=12.0):
         dt2 = time.perf_counter() - t1
         all_cores_value, all_cores_sample = d2 * steps / dt2, f"{d2} envs x {steps} steps ({dt2:.1f} s)"
     elif all_cores == cores:
-        all_cores_value, all_cores_sample = done_envs * steps / dt, "the same run: `cores` is the whole affinity mask"
+        all_cores_value, all_cores_sample = done_envs * steps / dt, "the same run: `cores` is all this process may use (min of affinity mask and cgroup CPU quota)"
     out = {
         "value": done_envs * steps / dt,
         "unit": "env-steps/s",

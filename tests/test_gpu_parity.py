@@ -610,7 +610,10 @@ def test_host_step_round_trip_matches_the_oracle(name, steps):
     rng = np.random.default_rng(17)
     for t in range(steps):
         a = rng.integers(0, 9, n).astype(np.int8)
-        r64, done, status, view, py, npw = vec.host_step(a, py, npw, rng_out=True, obs=obs, meta=meta)
+        # two steps in three leave the device's generators where the previous step left them (what the facade does while the caller's
+        # random / np.random are untouched): the streams then run on across block ends by the step kernel's own ring regeneration
+        keep = t % 3 != 0
+        r64, done, status, view, py, npw = vec.host_step(a, None if keep else py, None if keep else npw, rng_out=True, obs=obs, meta=meta)
         rw, dn, st = ref.step(a)
         ctx = f"{name} step {t}"
         assert status == st and done == dn and np.array_equal(r64, rw), ctx
@@ -625,6 +628,23 @@ def test_host_step_round_trip_matches_the_oracle(name, steps):
     with pytest.raises(abi.CtfLibraryError, match="ONE env"):
         big.host_step(None)
     big.close()
+
+
+def test_facade_with_private_device_streams_leaves_the_global_generators_alone():
+    """GridworldCtf(rng="device", seed=s): the env draws from its own device streams (seeded like random.seed(s); np.random.seed(s)),
+    the process-global generators are neither read nor advanced, and the trajectory is the reference's for that seed."""
+    case = Case("arena_random")
+    z = case.z
+    random.seed(999)
+    np.random.seed(999)
+    before = (random.getstate(), np.random.get_state())
+    env = pkg.GridworldCtf(rng="device", seed=case.meta["seed"], **case.kwargs)
+    for t in range(40):
+        _, rewards, done = env.step([int(a) for a in z["actions"][t]])
+        assert np.array_equal(env.grid, z["grid"][t]) and rewards == [float(r) for r in z["rewards"][t]]
+        assert np.array_equal(env.standardise_state(3, reverse_grid=True), case.unpack_obs(z["obs"][t])[3][None])
+    after = (random.getstate(), np.random.get_state())
+    assert after[0] == before[0] and np.array_equal(after[1][1], before[1][1]) and after[1][2] == before[1][2]
 
 
 def test_spawn_edge_status_bit_and_the_facades_index_error():
