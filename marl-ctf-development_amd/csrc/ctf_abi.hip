@@ -19,9 +19,6 @@ extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint6
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
 extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint32_t, int, hipStream_t);
 extern "C" int ctf_step_blocks(const DevCfg&);
-extern "C" int ctf_step_observe_fused_ok(const DevCfg&);
-extern "C" hipError_t ctf_launch_step_observe_small(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint32_t, int,
-                                                    uint8_t*, uint16_t*, uint32_t, hipStream_t);
 extern "C" int ctf_observe_uses_tiles(const DevCfg&, const uint8_t*);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint16_t*, uint32_t, int, hipStream_t);
@@ -363,12 +360,6 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
     // (The ring regeneration rides at the tail of the step launch.  Running it as a launch of its own on a second stream, beside
     // the render, was built and measured in round 3: the render lost more than the step kernel gained — 189-191 M against 198 M
     // env-steps/s, profiles/r03_side_stream_ablation.md.)
-    if (obs && meta && ctf_step_observe_fused_ok(h->d)) {
-        // a small batch: ONE launch — a block steps its 64 / W envs and renders them from LDS (k_step_observe_small; round 5)
-        HIP_TRY(ctf_launch_step_observe_small(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, 1, obs, meta,
-                                              resolve_reverse(h, reverse_mask), (hipStream_t)stream));
-        return CTF_OK;
-    }
     HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, 1, (hipStream_t)stream));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));

@@ -411,18 +411,25 @@ __device__ __forceinline__ void tail_block(const DevCfg& cfg, const DevPtrs& p, 
     (void)n_done;
 #endif
 }
+// 16 blocks (= waves) per CU fit by LDS: the register budget is held to the matching 4 waves per SIMD (128 VGPRs)
+template <bool METRICS, int W>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restrict__ rw32, double* __restrict__ rw64,
+       uint8_t* __restrict__ done_out, uint32_t flags, uint32_t phase, int n_step_blocks) {
+    constexpr int EPW = WAVE / W;  // envs per wave
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
 #ifndef STEP_TAIL_FIRST
 #define STEP_TAIL_FIRST 0  // 1 (measured, not shipped): the ring-regenerating blocks at the HEAD of the grid instead of its tail
 #endif
-// One wave steps the EPW = 64 / W envs of step block `sb` (GridworldCtf.step, gridworld_ctf.py:849-918): stage -> group_step -> write
-// back.  The body of k_step, and of the step phase of k_step_observe_small; `lds` holds the wave's EPW slots, which keep the envs'
-// final grid and record when it returns.
-template <bool METRICS, int W>
-__device__ __forceinline__ void step_wave_body(const DevCfg& cfg, const DevPtrs& p, const int8_t* __restrict__ actions, float* __restrict__ rw32,
-                                               double* __restrict__ rw64, uint8_t* __restrict__ done_out, uint32_t flags, int sb, int lane,
-                                               uint32_t* lds) {
-    constexpr int EPW = WAVE / W;  // envs per wave
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int n_tail_blocks = (int)gridDim.x - n_step_blocks;
+    const int sb = STEP_TAIL_FIRST ? (int)blockIdx.x - n_tail_blocks : (int)blockIdx.x;  // this step block's index
+    if (STEP_TAIL_FIRST ? sb < 0 : sb >= n_step_blocks) {
+        // ---- a TAIL block (see tail_block): these start as step blocks retire — the LDS is full until then
+        tail_block(cfg, p, STEP_TAIL_FIRST ? (int)blockIdx.x : sb - n_step_blocks, phase, lane, lds);
+        return;
+    }
     STEP_STAMP(0);
 #if STEP_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 8192)
@@ -565,23 +572,6 @@ __device__ __forceinline__ void step_wave_body(const DevCfg& cfg, const DevPtrs&
         }
     }
     STEP_STAMP(4);
-}
-
-// 16 blocks (= waves) per CU fit by LDS: the register budget is held to the matching 4 waves per SIMD (128 VGPRs)
-template <bool METRICS, int W>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restrict__ rw32, double* __restrict__ rw64,
-       uint8_t* __restrict__ done_out, uint32_t flags, uint32_t phase, int n_step_blocks) {
-    extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x;
-    const int n_tail_blocks = (int)gridDim.x - n_step_blocks;
-    const int sb = STEP_TAIL_FIRST ? (int)blockIdx.x - n_tail_blocks : (int)blockIdx.x;  // this step block's index
-    if (STEP_TAIL_FIRST ? sb < 0 : sb >= n_step_blocks) {
-        // ---- a TAIL block (see tail_block): these start as step blocks retire — the LDS is full until then
-        tail_block(cfg, p, STEP_TAIL_FIRST ? (int)blockIdx.x : sb - n_step_blocks, phase, lane, lds);
-        return;
-    }
-    step_wave_body<METRICS, W>(cfg, p, actions, rw32, rw64, done_out, flags, sb, lane, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -928,80 +918,6 @@ __global__ void __launch_bounds__(256) k_observe(DevCfg cfg, DevPtrs p, uint8_t*
 #else
             recw = ((const uint32_t*)(p.rec + (size_t)(e + e_stride) * cfg.RS))[rec_lane];
 #endif
-        }
-        __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // this env's LDS reads are done before the next env reuses the bitmap
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// step + observe as ONE launch for SMALL batches (round 5)
-// ------------------------------------------------------------------------------------------------
-// At 65 536 envs the two launches of ctf_step_observe are the right shape (a fused launch was 25 % slower there: DESIGN.md, HISTORY 3.1);
-// at a few thousand envs each of them is a latency-bound kernel of ~10 us behind a ~2.4 us dispatch gap, and the render cannot start
-// before the LAST env of the batch has been stepped.  Here a block is one step wave plus render waves: wave 0 steps the block's 64 / W
-// envs exactly as a k_step block does (step_wave_body: the slots keep the envs' final grid and record in LDS), the block meets at one
-// barrier, and its waves render those envs from the LDS slots with k_observe's per-env build and stream — a group's observation leaves
-// as soon as that group has been stepped, and the whole env-step is one dispatch.  Tail blocks (ring regeneration) ride at the end of
-// the grid as in k_step.  For grids of <= 16 x 16 cells (a lane's grid dword comes from the slot; 0_the_split, the arenas).
-template <bool METRICS, int W, int ALIGN>
-__global__ void __launch_bounds__(512) k_step_observe_small(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restrict__ rw32,
-                                                            double* __restrict__ rw64, uint8_t* __restrict__ done_out, uint32_t flags,
-                                                            uint32_t phase, int n_step_blocks, uint8_t* __restrict__ obs,
-                                                            uint16_t* __restrict__ meta, uint32_t reverse_mask, int step_bytes) {
-    constexpr int EPW = WAVE / W;
-    extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-    const int wpb = blockDim.x / WAVE;
-    const int sb = (int)blockIdx.x;
-    if (sb >= n_step_blocks) {  // a tail block: one wave's work
-        if (wave == 0) tail_block(cfg, p, sb - n_step_blocks, phase, lane, lds);
-        return;
-    }
-    const int N = cfg.N, M = cfg.M;
-    uint8_t* wl = (uint8_t*)lds + step_bytes + wave * obs_wave_bytes(cfg.RS, N, M, cfg.obs_bytes);
-    uint8_t* srec = wl;
-    uint16_t* mv = (uint16_t*)(wl + cfg.RS);
-    uint16_t* mstage = (uint16_t*)(wl + cfg.RS + OBS_MV_BYTES);
-    uint8_t* mlut = wl + cfg.RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
-    uint32_t* bits = (uint32_t*)(mlut + obs_meta_lut_bytes(N, M));
-    const ObsSlots slots = obs_slots(cfg, reverse_mask);
-    if (meta) obs_meta_lut(cfg, mlut, mv, lane);  // (the render waves build theirs while wave 0 steps)
-    if (wave == 0) step_wave_body<METRICS, W>(cfg, p, actions, rw32, rw64, done_out, flags, sb, lane, lds);
-    __syncthreads();  // the slots hold the stepped envs
-
-    const int env0 = sb * EPW, nvalid = min(EPW, cfg.n_envs - env0);
-    const int SLW = step_slot_bytes(cfg.GS, cfg.RS, N, METRICS) / 4, GW = cfg.GS / 4;
-    const int rec_lane = min(lane, cfg.RS / 4 - 1), grid_lane = min(lane, GW - 1);
-    for (int el = wave; el < nvalid; el += wpb) {
-        const int e = env0 + el;
-        const uint32_t* slot = lds + el * SLW;
-        const uint32_t cells = slot[grid_lane], recw = slot[GW + rec_lane];
-        obs_build_env(cfg, p, e, recw, cells, srec, mv, mstage, mlut, bits, slots, reverse_mask, lane, obs != nullptr, meta);
-        if (obs) {  // k_observe's stream: 1-KiB-aligned store instructions, eight per pass with their bitmap halfwords read first
-            const size_t base = (size_t)e * cfg.obs_bytes;
-            uint8_t* out = obs + base;
-            const uint16_t* hb = (const uint16_t*)bits;
-            const int nfull = cfg.obs_bytes >> 4, tail = cfg.obs_bytes & 15;
-            const int nchunks = nfull + (tail ? 1 : 0);
-            const int k0 = (ALIGN >= 16) ? -(int)(((base + (uintptr_t)obs) >> 4) & 63) : 0;
-            uint32_t ablate_acc = 0;
-            const int niter = (nchunks - k0 + WAVE - 1) / WAVE;
-            for (int it0 = 0; it0 < niter; it0 += OBS_UNROLL) {
-                uint32_t h[OBS_UNROLL];
-#pragma unroll
-                for (int u = 0; u < OBS_UNROLL; u++) {
-                    const int k = k0 + lane + (it0 + u) * WAVE;
-                    h[u] = (k >= 0 && k < nchunks) ? hb[k] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < OBS_UNROLL; u++) {
-                    const int k = k0 + lane + (it0 + u) * WAVE;
-                    if (k >= 0 && k < nchunks) obs_store_chunk<ALIGN>(out, h[u], k, nfull, tail, ablate_acc);
-                }
-            }
-            (void)ablate_acc;
         }
         __builtin_amdgcn_s_waitcnt(LGKM_ONLY);  // this env's LDS reads are done before the next env reuses the bitmap
         __builtin_amdgcn_wave_barrier();
@@ -1521,57 +1437,6 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
     if (align == 16) hipLaunchKernelGGL(k_observe<16>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
     else if (align == 4) hipLaunchKernelGGL(k_observe<4>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
     else hipLaunchKernelGGL(k_observe<1>, grid, block, sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
-    return hipGetLastError();
-}
-// ---- the fused small-batch launch (k_step_observe_small).  ctf_step_observe_fused_ok: may / should this handle's step + observe be one launch?
-template <bool METRICS, int W>
-static void launch_fused_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags,
-                           uint32_t phase, bool with_tail, uint8_t* obs, uint16_t* meta, uint32_t reverse_mask, hipStream_t st) {
-    constexpr int EPW = WAVE / W;
-    const int nstep = (cfg.n_envs + EPW - 1) / EPW;
-    const int ntail = with_tail ? (2 * cfg.n_envs + STEP_TAIL_PAIRS - 1) / STEP_TAIL_PAIRS : 0;
-    int step_bytes = EPW * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
-    if (step_bytes < 2 * CTF_MT_N * 4) step_bytes = 2 * CTF_MT_N * 4;  // a tail block stages two rings
-    step_bytes = (step_bytes + 15) & ~15;
-    const int wpb = EPW < 8 ? EPW : 8;  // one render wave per env of the block, at most eight
-    const size_t sh = (size_t)step_bytes + (size_t)wpb * obs_wave_bytes(cfg.RS, cfg.N, cfg.M, cfg.obs_bytes);
-    const dim3 grid(nstep + ntail), block(wpb * WAVE);
-    const int align = observe_align(cfg, obs);
-#define CTF_FUSED_LAUNCH(A)                                                                                                             \
-    do {                                                                                                                                \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_step_observe_small<METRICS, W, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((k_step_observe_small<METRICS, W, A>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags, phase, nstep, obs, meta, \
-                           reverse_mask, step_bytes);                                                                                   \
-    } while (0)
-    if (align == 16) CTF_FUSED_LAUNCH(16);
-    else if (align == 4) CTF_FUSED_LAUNCH(4);
-    else CTF_FUSED_LAUNCH(1);
-#undef CTF_FUSED_LAUNCH
-}
-template <bool METRICS>
-static void launch_fused_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done,
-                           uint32_t flags, uint32_t phase, bool with_tail, uint8_t* obs, uint16_t* meta, uint32_t rm, hipStream_t st) {
-    if (w <= 1) launch_fused_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, obs, meta, rm, st);
-    else if (w == 2) launch_fused_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, obs, meta, rm, st);
-    else if (w == 4) launch_fused_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, obs, meta, rm, st);
-    else launch_fused_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, obs, meta, rm, st);
-}
-#ifndef CTF_FUSED_MAX_ENVS
-#define CTF_FUSED_MAX_ENVS 8192  // above this the two launches win (measured: profiles/r05_fused_small_batch.md)
-#endif
-extern "C" int ctf_step_observe_fused_ok(const DevCfg& cfg) {
-    if (cfg.GS / 4 > WAVE) return 0;  // G <= 16: a lane's grid dword comes from the step wave's LDS slot
-    const char* fenv = getenv("CTF_FUSED_SMALL");  // 0 / 1: never / whenever possible (tests, profiling)
-    if (fenv) return atoi(fenv) != 0;
-    return cfg.n_envs <= CTF_FUSED_MAX_ENVS;
-}
-extern "C" hipError_t ctf_launch_step_observe_small(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                                                    uint8_t* done, uint32_t flags, uint32_t phase, int with_tail, uint8_t* obs, uint16_t* meta,
-                                                    uint32_t reverse_mask, hipStream_t st) {
-    const int w = step_lanes(cfg);
-    const bool tail = with_tail && cfg.rng_refill_every;
-    if (cfg.log_metrics) launch_fused_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, phase, tail, obs, meta, reverse_mask, st);
-    else launch_fused_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, phase, tail, obs, meta, reverse_mask, st);
     return hipGetLastError();
 }
 extern "C" hipError_t ctf_launch_observe_codes(const DevCfg& cfg, const DevPtrs& p, uint8_t* codes, uint16_t* meta, uint16_t* selfcells,

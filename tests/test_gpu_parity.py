@@ -630,72 +630,6 @@ def test_host_step_round_trip_matches_the_oracle(name, steps):
     big.close()
 
 
-@pytest.mark.parametrize("name,n_envs,w,metrics", [("split_random", 4096, 0, True), ("split_random", 301, 0, True), ("arena_stress", 130, 0, True),
-                                                  ("arena_random", 517, 0, False), ("donut_1v1", 333, 0, True), ("fuzz_13", 64, 0, True),
-                                                  ("split_random", 200, 1, True), ("arena_stress", 99, 2, True), ("arena_stress", 70, 8, True),
-                                                  ("syn_axis1_drop", 1, 0, True)])
-def test_fused_small_batch_step_observe_equals_the_two_launches(name, n_envs, w, metrics, monkeypatch):
-    """Small batches take step + observe as ONE launch (k_step_observe_small: a block steps its envs and renders them from LDS);
-    CTF_FUSED_SMALL=0 / 1 forces the two-launch / the fused form.  Same seeds, same actions: rewards (f64 and f32), done, every
-    observation byte, every metadata row after every step, and at the end counters, full state views and both generators' states must
-    be equal between the two forms — and equal to the oracle on a sample.  Covers ragged last blocks, every lane width, metrics off,
-    auto-reset across an episode end, blocks that are 16-, 4- and 2-byte aligned, and a batch of one."""
-    case = Case(name)
-    kw = dict(case.kwargs, GAME_STEPS=min(case.kwargs.get("GAME_STEPS", 500), 60))
-    if w:
-        monkeypatch.setenv("CTF_STEP_W", str(w))
-    seeds = np.arange(n_envs, dtype=np.uint64) * 7 + 3
-    vecs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("CTF_FUSED_SMALL", mode)
-        vecs[mode] = pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=seeds, log_metrics=metrics, tune_placement=False, **kw)
-    cfg, _ = cfgmod.build_config(kw, log_metrics=metrics)
-    sample = sorted({0, n_envs - 1, n_envs // 2, min(63, n_envs - 1), min(64, n_envs - 1)})
-    refs = {e: oracle.OracleEnv(cfg) for e in sample}
-    for e, r in refs.items():
-        r.seed(int(seeds[e]), int(seeds[e]))
-    n = case.n
-    acts = torch.empty((n_envs, n), dtype=torch.int8, device=vecs["1"].device)
-    dead = set()
-    for t in range(90):
-        vecs["1"].random_actions(acts, seed=0xF05E, step=t)
-        out = {}
-        for mode, vec in vecs.items():
-            monkeypatch.setenv("CTF_FUSED_SMALL", mode)
-            rw, dn, ob, mt = vec.step_observe(acts, auto_reset=True, want_f64=True)
-            out[mode] = (rw.clone(), vec.rewards64.clone(), dn.clone(), ob.clone(), mt.clone())
-        a, b = out["1"], out["0"]
-        ctx = f"{name} E={n_envs} step {t}"
-        assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1].view(torch.int64), b[1].view(torch.int64)), ctx + ": rewards"
-        assert torch.equal(a[2], b[2]), ctx + ": done"
-        assert torch.equal(a[3], b[3]), ctx + ": observations"
-        assert torch.equal(a[4].view(torch.int16), b[4].view(torch.int16)), ctx + ": metadata"
-        host_a = acts.cpu().numpy()
-        for e, r in refs.items():
-            if e in dead:
-                continue
-            if r.get_state().done:
-                r.reset()
-            rw, dn, status = r.step(host_a[e])
-            if status:  # (no open respawn cell on a random small map: the reference raises there)
-                dead.add(e)
-                continue
-            ro, rm = r.observe()
-            assert np.array_equal(a[1][e].cpu().numpy(), rw) and int(a[2][e]) == int(dn), ctx + f" env {e} vs oracle"
-            assert np.array_equal(a[3][e].cpu().numpy(), ro) and np.array_equal(a[4][e].cpu().numpy().view(np.uint16), rm.view(np.uint16)), ctx + f" env {e} vs oracle"
-    sa, sb = vecs["1"], vecs["0"]
-    for x, y in zip(sa.counters(), sb.counters()):
-        assert torch.equal(x, y)
-    pa, na = sa.get_rng_states()
-    pb, nb = sb.get_rng_states()
-    assert torch.equal(pa, pb) and torch.equal(na, nb)
-    for e in sample:
-        _state_equal(view_arrays(sa.get_state(e), n, case.g), view_arrays(sb.get_state(e), n, case.g), f"{name} env {e} final state")
-    assert (sa.status() & ~abi.ST_NO_RESPAWN) == 0 and (sb.status() & ~abi.ST_NO_RESPAWN) == 0
-    sa.close()
-    sb.close()
-
-
 def test_facade_with_private_device_streams_leaves_the_global_generators_alone():
     """GridworldCtf(rng="device", seed=s): the env draws from its own device streams (seeded like random.seed(s); np.random.seed(s)),
     the process-global generators are neither read nor advanced, and the trajectory is the reference's for that seed."""
