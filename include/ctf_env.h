@@ -242,10 +242,10 @@ int ctf_set_state(ctf_env* env, int32_t env_index, const ctf_state_view* host_in
  * rollout loop over GridworldCtf does per step (ppo.py:59-98): step(actions) (gridworld_ctf.py:849-918), then standardise_state(i) +
  * get_env_metadata(i) for every agent (:975-1069), with the process-global generators handed in and back (random.getstate() /
  * np.random.get_state(); the reference draws from them inside step).  For a handle of n_envs == 1 (CTF_E_INVALID otherwise).
- * Everything — the hand-over of both generator states, the step, the render, the state read-back — is enqueued on `stream` behind
- * ONE host-to-device and in front of ONE device-to-host copy of a staging block the handle owns (pinned on the host side), and the
- * call waits for the stream once: round 5 measured 408 us per env step for the same work through ctf_set_rng_states + ctf_step +
- * ctf_get_rng_states + ctf_observe + ctf_get_state + ctf_status with a wait behind each.
+ * Everything — the hand-over of both generator states, the step, the render, the state read-back — is enqueued on `stream` as kernels
+ * that read their inputs from, and write their outputs into, ONE pinned, device-mapped host block the handle owns (no copy operations),
+ * and the call waits for the stream once: round 5 measured 408 us per env step for the same work through ctf_set_rng_states + ctf_step
+ * + ctf_get_rng_states + ctf_observe + ctf_get_state + ctf_status with a wait behind each.
  * All pointers are HOST pointers; any OUT pointer may be NULL (not wanted).
  *   actions_host    int8 [N], or NULL: no step is made (state, observation and generator states are still returned: reset())
  *   py_mt625_in / np_mt625_in   uint32 [625] (624 words + position) to install BEFORE the step, or NULL (keep the device's)

@@ -39,9 +39,9 @@ struct ctf_env {
     uint64_t* seed_scratch;  // device, 2*E u64
     uint32_t* rng_scratch;   // device, 2 x 625 u32: one env's two generators in the standard form (ctf_set/get_rng_state)
     uint32_t step_phase;     // counts the step launches (k_step's tail blocks: which share of the stale rings this launch takes)
-    // ctf_host_step (n_envs == 1): one device block + its pinned host twin, allocated on first use
-    uint8_t* hio_dev;
-    uint8_t* hio_host;
+    // ctf_host_step (n_envs == 1): one pinned, device-mapped host block (allocated on first use) that the kernels read and write directly
+    uint8_t* hio_dev;   // the DEVICE address of that block (hipHostGetDevicePointer)
+    uint8_t* hio_host;  // its host address
 };
 
 // Layout of the ctf_host_step block (byte offsets; every segment 16-byte aligned, the observation 256-byte aligned).
@@ -118,7 +118,6 @@ static void free_all(ctf_env* h) {
     (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
     (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch); (void)hipFree(h->p.rngready);
     (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib);
-    if (h->hio_dev) (void)hipFree(h->hio_dev);
     if (h->hio_host) (void)hipHostFree(h->hio_host);
     delete h;
 }
@@ -489,22 +488,27 @@ extern "C" int ctf_host_step(ctf_env* h, const int8_t* actions, const uint32_t* 
     DeviceGuard guard(h->device);
     const DevCfg& d = h->d;
     const HostIo L = host_io_layout(d);
-    if (!h->hio_dev) {
-        if (hipMalloc((void**)&h->hio_dev, L.end) != hipSuccess) return fail(CTF_E_NOMEM, "hipMalloc(%zu) failed", L.end);
-        if (hipHostMalloc((void**)&h->hio_host, L.end, hipHostMallocDefault) != hipSuccess) {
-            (void)hipFree(h->hio_dev);
-            h->hio_dev = nullptr;
+    if (!h->hio_host) {
+        // pinned, mapped, coherent host memory: the kernels below read their inputs from it and write their outputs into it across the
+        // bus (a few KB in, ~50 KB out) — no copy operations in the stream; a kernel's stores are visible to the host when the stream
+        // has been waited for
+        void* dev = nullptr;
+        if (hipHostMalloc((void**)&h->hio_host, L.end, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
             return fail(CTF_E_NOMEM, "hipHostMalloc(%zu) failed", L.end);
+        if (hipHostGetDevicePointer(&dev, h->hio_host, 0) != hipSuccess) {
+            (void)hipHostFree(h->hio_host);
+            h->hio_host = nullptr;
+            return fail(CTF_E_HIP, "hipHostGetDevicePointer failed");
         }
-        HIP_TRY(hipMemset(h->hio_dev, 0, L.end));
+        h->hio_dev = (uint8_t*)dev;
+        memset(h->hio_host, 0, L.end);
     }
     hipStream_t st = (hipStream_t)stream;
     uint8_t *hd = h->hio_dev, *hh = h->hio_host;
-    // host -> device: actions and the generator states to install, one copy
+    // inputs: actions and the generator states to install (the previous call has waited for the stream: nothing reads the block now)
     if (actions) memcpy(hh + L.actions, actions, (size_t)d.N);
     if (py_in) memcpy(hh + L.py_in, py_in, (CTF_MT_N + 1) * 4);
     if (np_in) memcpy(hh + L.np_in, np_in, (CTF_MT_N + 1) * 4);
-    if (actions || py_in || np_in) HIP_TRY(hipMemcpyAsync(hd, hh, L.in_end, hipMemcpyHostToDevice, st));
     if (py_in || np_in) {
         HIP_TRY(ctf_launch_import_rng(d, h->p, py_in ? (const uint32_t*)(hd + L.py_in) : nullptr,
                                       np_in ? (const uint32_t*)(hd + L.np_in) : nullptr, 0, 1, st));
@@ -522,9 +526,7 @@ extern "C" int ctf_host_step(ctf_env* h, const int8_t* actions, const uint32_t* 
                                    resolve_reverse(h, reverse_mask), h->n_cus, st));
     hipLaunchKernelGGL(k_host_pack, dim3(1), dim3(256), 0, st, d, h->p, hd, L);
     HIP_TRY(hipGetLastError());
-    // device -> host: everything in one copy; the only wait of the call
-    HIP_TRY(hipMemcpyAsync(hh + L.out, hd + L.out, L.end - L.out, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st));  // the only wait of the call: every output already lies in host memory
     if (rewards && actions) memcpy(rewards, hh + L.rw64, (size_t)d.N * 8);
     const uint32_t* ds = (const uint32_t*)(hh + L.done_status);
     if (status) *status = ds[1];
