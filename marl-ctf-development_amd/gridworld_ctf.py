@@ -108,8 +108,9 @@ class VecGridworldCtf:
         self._tune_placement = bool(tune_placement)
         import os
 
-        self._placement_tries = int(placement_tries if placement_tries is not None else os.environ.get("CTF_PLACEMENT_TRIES", 128))
+        self._placement_tries = int(placement_tries if placement_tries is not None else os.environ.get("CTF_PLACEMENT_TRIES", 256))
         self._placement_gib = float(placement_gib if placement_gib is not None else os.environ.get("CTF_PLACEMENT_GIB", 16))
+        self._placement_seconds = float(os.environ.get("CTF_PLACEMENT_SECONDS", 1.0))
         self.placement_probe_ms = None
         self.placement_fill_ms = None
         self.placement = None  # what the placement search found: kind fast / intermediate / slow, render / fill ratio, ...
@@ -143,13 +144,14 @@ class VecGridworldCtf:
         nor 45 % of the free device memory: a co-resident policy / learner is not starved while this searches.  A rejected candidate
         goes back to the driver at once (``torch.cuda.empty_cache``); the next allocation is of an independent kind even when nothing
         is held in between (tools/placement_probe2.py, profiles/r03_placement_search_strategies.txt: holding the rejected ones, as
-        round 2 did, finds fast buffers no more often), so the search can afford ``placement_tries`` candidates (default 128;
+        round 2 did, finds fast buffers no more often), so the search can afford ``placement_tries`` candidates (default 256;
         CTF_PLACEMENT_TRIES) at a few milliseconds each.  An allocation failure ends the search with what it has.
 
         The search stops at a candidate whose render takes at most ``good_enough`` x the time of a plain ``fill_`` of the same
-        buffer (which does not depend on the buffer's kind), or eight tries after it first holds one that is 7 % faster than the slowest
-        it has seen — the kinds form two clusters (render / fill 1.05-1.12 and 1.20-1.27 over this round's boxes, the fill itself 0.234-0.243
-        ms from box to box), so that is "both kinds seen, the fast one in hand".  ``self.placement`` says what was found."""
+        buffer (which does not depend on the buffer's kind), or — once it holds one that is 7 % faster than the slowest it has seen: the
+        kinds form two clusters (render / fill 1.04-1.12 and 1.20-1.27, the fill itself 0.234-0.243 ms from box to box), so
+        that is "both kinds seen, a fast one in hand" — when ``placement_seconds`` of wall time are used up.  ``self.placement`` says what
+        was found."""
         import time
 
         torch = _torch()
@@ -178,14 +180,15 @@ class VecGridworldCtf:
         best_ms = probe(best)
         times = [best_ms]
         fill_ms = timed(lambda: best.fill_(0))
-        polish = 8  # once a buffer of the good cluster is in hand: a few more tries for its best members (0.253-0.266 ms on the arena)
+        # Once a buffer of the good cluster is in hand the search goes on for its BEST members — the cluster itself spans render / fill
+        # 1.04-1.10 (0.246-0.264 ms on the arena; round 5: one box's two runs kept 0.2614 and 0.2497 = 199 and 207 M env-steps/s) and a
+        # candidate costs 1.5 ms — until one is good enough, the tries are used up, or `placement_seconds` (default 1.0;
+        # CTF_PLACEMENT_SECONDS) have gone by.  (Round 3's rule — eight more tries — found a second good one 4 times in 10.)
         for _ in range(tries - 1):
             if best_ms <= good_enough * fill_ms:
                 break
-            if best_ms <= 0.93 * max(times):
-                if polish == 0:
-                    break
-                polish -= 1
+            if best_ms <= 0.93 * max(times) and time.perf_counter() - t0 > self._placement_seconds:
+                break
             try:
                 cand = torch.empty_like(best)
             except torch.cuda.OutOfMemoryError:
