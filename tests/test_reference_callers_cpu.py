@@ -44,11 +44,12 @@ def ref():
     sys.modules.update(mods)
     try:
         import ppo as ref_ppo
+        import agent_network as ref_agent
     finally:
         sys.path[:] = saved
         for m in ("gridworld_ctf", "scenarios", "utils", "ppo", "agent_network"):
             sys.modules.pop(m, None)
-    yield types.SimpleNamespace(Env=Ref, scn=scn, ppo=ref_ppo, utils=mods["utils"])
+    yield types.SimpleNamespace(Env=Ref, scn=scn, ppo=ref_ppo, utils=mods["utils"], agent_network=sys.modules.get("agent_network") or ref_agent)
     os.chdir(cwd)
 
 
@@ -137,3 +138,33 @@ def test_the_references_duel_drives_both_classes_to_the_same_result(ref, facade,
     random.setstate(st[0])
     np.random.set_state(st[1])
     assert twin.step(acts)[1] == r1 and np.array_equal(twin.grid, env_mine.grid)
+
+
+def test_the_references_rollout_with_the_references_own_network_on_both_classes(ref, facade):
+    """The same with the reference's own ``agent_network.Agent`` as agent and opponent (random weights, sampling through torch's
+    generator): under the same ``torch.manual_seed`` the two classes feed it identical observations, so it draws identical actions —
+    every rollout tensor, log-probs and values included, equal bit for bit."""
+    case = Case("script_8_arena")
+    steps = 25
+
+    def collect(make_env):
+        random.seed(7)
+        np.random.seed(7)
+        torch.manual_seed(7)
+        env = make_env()
+        dims = env.get_env_dims()
+        agent = ref.agent_network.Agent(9, dims[0][0], env.GRID_SIZE, dims[2][0])
+        opponent = ref.agent_network.Agent(9, dims[0][0], env.GRID_SIZE, dims[2][0])
+        tr = ref.ppo.PPOTrainer(types.SimpleNamespace(num_steps=steps, device="cpu"), dims[0], dims[2])
+        tr.device, tr.team_to_train, tr.reverse_grid = "cpu", 1, True
+        tr.num_agents_per_team = env.N_AGENTS // 2
+        tr.num_steps = steps * tr.num_agents_per_team
+        tr.max_rewards = -np.inf
+        return [t.detach().numpy() for t in tr.get_single_rollout(env, agent, opponent)], torch.get_rng_state()
+
+    want, tw = collect(lambda: ref.Env(SCENARIO=_ref_scenario(ref, case), **_kwargs(case)))
+    got, tg = collect(lambda: facade(SCENARIO=case.kwargs["SCENARIO"], **_kwargs(case)))
+    for a, b in zip(want, got):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert torch.equal(tw, tg)
+    assert len(np.unique(want[2])) > 3  # (the network did choose among several actions)
