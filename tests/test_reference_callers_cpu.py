@@ -168,3 +168,37 @@ def test_the_references_rollout_with_the_references_own_network_on_both_classes(
         assert a.shape == b.shape and np.array_equal(a, b)
     assert torch.equal(tw, tg)
     assert len(np.unique(want[2])) > 3  # (the network did choose among several actions)
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+def test_the_references_whole_training_loop_trains_the_same_network_on_both_classes(ref, facade, parallel):
+    """``PPOTrainer.train_ppo`` (ppo.py:250-478) — rollouts of several envs per update (sequentially, or as the reference's Ray tasks with
+    ``ray.remote`` stubbed to a direct call), GAE, the PPO update with its ``np.random.shuffle`` minibatches, learning-rate annealing — run
+    UNCHANGED for three updates on the reference env and on this repo's class: the returned reward history and every parameter of the
+    trained network are equal bit for bit, and so is where all three generators (random, np.random, torch) stand afterwards."""
+    case = Case("script_8_arena")
+    args = types.SimpleNamespace(use_wandb_ppo=False, device="cpu", learning_rate=2.5e-4, num_steps=12, num_envs=3, num_minibatches=2, total_timesteps=36,
+                                 anneal_lr=True, parallel_rollouts=parallel, update_epochs=2, clip_coef=0.2, norm_adv=True, clip_vloss=True, ent_coef=0.01,
+                                 vf_coef=0.5, max_grad_norm=0.5, target_kl=None, gamma=0.99, gae_lambda=0.95, gae=True, seed=1, cuda=False,
+                                 torch_deterministic=True, wandb_project_name="", wandb_entity="")
+    sys.modules["ray"].remote = lambda f: types.SimpleNamespace(remote=f)  # a Ray task = the call itself; ray.get = identity
+    sys.modules["ray"].get = lambda xs: xs
+
+    def train(make_env):
+        random.seed(3)
+        np.random.seed(3)
+        torch.manual_seed(3)
+        env = make_env()
+        dims = env.get_env_dims()
+        agent = ref.agent_network.Agent(9, dims[0][0], env.GRID_SIZE, dims[2][0])
+        opponent = ref.agent_network.Agent(9, dims[0][0], env.GRID_SIZE, dims[2][0])
+        tr = ref.ppo.PPOTrainer(args, dims[0], dims[2])
+        history = tr.train_ppo(args, env, agent, opponent, train_team1=True, verbose=False)
+        return history, [p.detach().numpy().copy() for p in agent.parameters()], _rng_state(), torch.get_rng_state()
+
+    hw, pw, rw, tw = train(lambda: ref.Env(SCENARIO=_ref_scenario(ref, case), **_kwargs(case)))
+    hg, pg, rg, tg = train(lambda: facade(SCENARIO=case.kwargs["SCENARIO"], **_kwargs(case)))
+    assert hw == hg and len(hw) == 3
+    for a, b in zip(pw, pg):
+        assert np.array_equal(a, b)
+    assert rg[0] == rw[0] and np.array_equal(rg[1], rw[1]) and rg[2] == rw[2] and torch.equal(tw, tg)
