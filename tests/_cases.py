@@ -114,3 +114,40 @@ def spawn_edge_kwargs():
                 AGENT_STARTING_POSITIONS={0: (3, 3), 1: (3, 4)}, BLOCK_TILE_SLICES=blocks, DESTRUCTIBLE_TILE_SLICES=[])
     return dict(GRID_SIZE=7, AGENT_CONFIG={0: {"team": 0, "type": 0}, 1: {"team": 1, "type": 0}}, GAME_STEPS=50, MAP_SYMMETRY_CHECK=False,
                 TAG_PROBABILITY=1.0, AGENT_TYPE_HP={0: 1, 1: 1, 2: 1, 3: 1}, AGENT_TYPE_DAMAGE={0: 1, 1: 1, 2: 1, 3: 1}, SCENARIO=scen)
+
+
+def wild_config(rng):
+    """A configuration OUTSIDE what the shipped maps and scripts use, still inside what the reference's class accepts: unequal teams
+    (down to 1 v N-1), CAPTURE_POSITIONS away from the flags, spawn windows that touch flags / walls / the high edges, agent types that
+    deal no damage, TAG_PROBABILITY 0, healing beyond the cap, free vaults, 4x4 .. 10x10 grids crowded with up to 8 agents.
+    -> (scenario dict, kwargs without SCENARIO) or None when the draw has no room for the agents."""
+    G = int(rng.integers(4, 11))
+    N = int(rng.integers(2, 9))
+    teams = [int(t) for t in rng.integers(0, 2, N)]
+    if len(set(teams)) < 2:
+        teams[0], teams[1] = 0, 1
+    cells = [(r, c) for r in range(G) for c in range(G)]
+    rng.shuffle(cells)
+    tup = lambda p: (int(p[0]), int(p[1]))
+    f0, f1 = tup(cells[0]), tup(cells[1])
+    inner = [tup(p) for p in cells if p[0] >= 1 and p[1] >= 1 and tup(p) not in (f0, f1)]
+    s0, s1 = inner[0], inner[1]  # (row / column 0 is the one documented difference: tests/golden/fuzz_edge0_*, spawn_edge_kwargs)
+    c0, c1 = (tup(cells[4]), tup(cells[5])) if rng.random() < 0.5 else (f0, f1)
+    rest = [tup(p) for p in cells[2:] if tup(p) not in (f0, f1, s0, s1)]
+    nb, nd = int(rng.integers(0, G)), int(rng.integers(0, G))
+    blocks, destr, starts = rest[:nb], rest[nb:nb + nd], rest[nb + nd:nb + nd + N]
+    if len(starts) < N:
+        return None
+    types = [int(t) for t in rng.integers(0, min(4, N), N)]  # (type id < N: get_env_metadata indexes agent_hp by type id)
+    scen = dict(SCENARIO_NAME="Wild", GRID_SIZE=G, FLIP_AXIS=[None, 0, 1, 2][int(rng.integers(0, 4))], FLAG_POSITIONS={0: f0, 1: f1},
+                CAPTURE_POSITIONS={0: c0, 1: c1}, SPAWN_POSITIONS={0: s0, 1: s1}, AGENT_STARTING_POSITIONS=dict(enumerate(starts)),
+                BLOCK_TILE_SLICES=blocks, DESTRUCTIBLE_TILE_SLICES=destr)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    hp = pick([0.25, 0.5, 1.0])
+    kw = dict(GRID_SIZE=G, AGENT_CONFIG={i: {"team": teams[i], "type": types[i]} for i in range(N)}, GAME_STEPS=int(rng.integers(20, 80)),
+              MAP_SYMMETRY_CHECK=False, HOME_FLAG_CAPTURE=bool(rng.integers(0, 2)), DROP_FLAG_WHEN_NO_HP=bool(rng.integers(0, 2)),
+              USE_ADJUSTED_REWARDS=bool(rng.integers(0, 2)), TAG_PROBABILITY=pick([0.0, 0.3, 1.0]),
+              AGENT_TYPE_HP={0: 10 * hp, 1: 8 * hp, 2: 8 * hp, 3: 7 * hp}, AGENT_TYPE_DAMAGE={0: pick([0, 1]), 1: 0.5, 2: pick([0, 0.5]), 3: 1},
+              GUARDIAN_DAMAGE_MULTIPLIER=pick([1.0, 5.0]), VAULT_HP_COST=pick([0.0, 0.25, 1.25]), VAULT_MIN_HP=pick([0.0, 0.5, 2.5]),
+              AGENT_HP_HEALING_PER_STEP=pick([0.0, 0.1, 0.25, 1.5]))
+    return scen, kw

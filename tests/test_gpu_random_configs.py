@@ -95,3 +95,62 @@ def test_random_config_matches_oracle(g, n, n_envs):
                 assert np.array_equal(a_[k], b_[k]), f"G={g} N={n} env {e} final {k}"
             break
     vec.close()
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_wild_configs_match_the_oracle(block):
+    """Configurations outside what the shipped maps and scripts use (tests/_cases.py wild_config: unequal teams down to 1 v N-1, capture
+    cells away from the flags, types that deal no damage, TAG_PROBABILITY 0, healing past the cap, free vaults, 4x4 grids with eight
+    agents) — the same generator the build-container test runs against the LIVE reference (tests/test_oracle_vs_live_reference.py):
+    HIP path vs oracle, 48 envs each, every step rewards (f64) / done / all observations and metadata rows, at the end the full state
+    views and both generators' states of every env that never ran out of respawn cells."""
+    from _cases import abi, wild_config
+
+    rng = np.random.default_rng(888_000 + block)
+    done_cfgs = 0
+    for trial in range(6):
+        drawn = wild_config(rng)
+        if drawn is None:
+            continue
+        scen, kw = drawn
+        kw = dict(kw, SCENARIO=scen)
+        n, g = len(kw["AGENT_CONFIG"]), scen["GRID_SIZE"]
+        cfg, _ = cfgmod.build_config(kw, log_metrics=True)
+        n_envs = 48
+        seeds = np.arange(n_envs, dtype=np.uint64) * 13 + 1000 * block + trial
+        vec = pkg.VecGridworldCtf(n_envs, device=0, py_seeds=seeds, np_seeds=seeds, log_metrics=True, **kw)
+        refs = [oracle.OracleEnv(cfg) for _ in range(n_envs)]
+        for e, r in enumerate(refs):
+            r.seed(int(seeds[e]), int(seeds[e]))
+        acts = torch.empty((n_envs, n), dtype=torch.int8, device=vec.device)
+        alive = np.ones(n_envs, bool)
+        for t in range(kw["GAME_STEPS"] + 6):
+            vec.random_actions(acts, seed=4711, step=t)
+            rewards, done, obs, meta = vec.step_observe(acts, auto_reset=True, want_f64=True)
+            a, r64, d = acts.cpu().numpy(), vec.rewards64.cpu().numpy(), done.cpu().numpy()
+            o, m = obs.cpu().numpy(), meta.cpu().numpy().view(np.uint16)
+            for e, r in enumerate(refs):
+                if not alive[e]:
+                    continue
+                if r.get_state().done:
+                    r.reset()
+                rw, dn, status = r.step(a[e])
+                if status:
+                    alive[e] = False
+                    continue
+                ro, rm = r.observe()
+                ctx = f"block {block} trial {trial} (G={g} N={n}) env {e} step {t}"
+                assert np.array_equal(r64[e], rw) and int(d[e]) == int(dn), ctx
+                assert np.array_equal(o[e], ro) and np.array_equal(m[e], rm.view(np.uint16)), ctx
+        for e in range(n_envs):
+            if alive[e]:
+                a_, b_ = view_arrays(vec.get_state(e), n, g), view_arrays(refs[e].get_state(), n, g)
+                for k in ("grid", "pos", "hp", "has_flag", "inv", "perm", "metrics", "visitation", "step_count", "team_captures"):
+                    assert np.array_equal(np.asarray(a_[k]), np.asarray(b_[k])), f"block {block} trial {trial} env {e} final {k}"
+                py, npw = vec.get_rng_state(e)
+                rpy, rnp = refs[e].get_rng_state()
+                assert np.array_equal(py, rpy) and np.array_equal(npw, rnp), f"block {block} trial {trial} env {e} generators"
+        assert (vec.status() & ~abi.ST_NO_RESPAWN) == 0
+        vec.close()
+        done_cfgs += 1
+    assert done_cfgs >= 3
