@@ -706,9 +706,12 @@ def test_facade_is_a_drop_in_for_the_reference_api():
     # travels by value like the reference env does under Ray (deepcopy / pickle), continuing identically
     twin = copy.deepcopy(env)
     blob = pickle.loads(pickle.dumps(env))
+    import cloudpickle  # what Ray moves its task arguments with (the reference's env only survives cloudpickle)
+
+    cblob = cloudpickle.loads(cloudpickle.dumps(env))
     st_py, st_np = random.getstate(), np.random.get_state()
     out_a = env.step([int(a) for a in z["actions"][60]])
-    for other in (twin, blob):
+    for other in (twin, blob, cblob):
         random.setstate(st_py)
         np.random.set_state(st_np)
         out_b = other.step([int(a) for a in z["actions"][60]])
