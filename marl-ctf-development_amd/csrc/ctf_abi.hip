@@ -455,8 +455,21 @@ extern "C" int ctf_get_state(ctf_env* h, int32_t e, ctf_state_view* out) {
 // ---- ctf_host_step: one env, host memory on both sides ------------------------------------------------------------------------
 // Gathers what a host view of env 0 needs (grid, record, counters, visitation base maps and log) next to the step's outputs, so
 // that ONE device-to-host copy brings everything back; reads and clears the sticky status word.
-__global__ void __launch_bounds__(256) k_host_pack(DevCfg d, DevPtrs p, uint8_t* io, HostIo L) {
+// py_out / np_out: also the two generators in the standard form (624 words of the current ring + the position: what k_export_rng
+// writes), so that the hand-back needs no launch of its own.
+__global__ void __launch_bounds__(256) k_host_pack(DevCfg d, DevPtrs p, uint8_t* io, HostIo L, uint32_t* py_out, uint32_t* np_out) {
     const int t = threadIdx.x;
+    {
+        uint32_t* dst[2] = {py_out, np_out};
+        const uint32_t* src[2] = {p.mt_py, p.mt_np};
+        for (int k = 0; k < 2; k++) {
+            if (!dst[k]) continue;  // uniform
+            const uint32_t rp = p.rngpos[k];
+            const uint32_t* in = src[k] + (size_t)CTF_RP_CUR(rp) * CTF_MT_N;
+            for (int i = t; i < CTF_MT_N; i += 256) dst[k][i] = in[i];
+            if (t == 0) dst[k][CTF_MT_N] = CTF_RP_POS(rp);
+        }
+    }
     for (int k = t; k < d.GS; k += 256) io[L.grid + k] = p.grid[k];
     for (int k = t; k < d.RS; k += 256) io[L.rec + k] = p.rec[k];
     if (d.log_metrics) {
@@ -518,13 +531,11 @@ extern "C" int ctf_host_step(ctf_env* h, const int8_t* actions, const uint32_t* 
     if (actions)
         HIP_TRY(ctf_launch_step(d, h->p, (const int8_t*)(hd + L.actions), nullptr, (double*)(hd + L.rw64), hd + L.done_status, flags,
                                 h->step_phase++, 1, st));
-    if (py_out || np_out)
-        HIP_TRY(ctf_launch_export_rng(d, h->p, py_out ? (uint32_t*)(hd + L.py_out) : nullptr, np_out ? (uint32_t*)(hd + L.np_out) : nullptr,
-                                      0, 1, st));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(d, h->p, obs ? hd + L.obs : nullptr, meta ? (uint16_t*)(hd + L.meta) : nullptr,
                                    resolve_reverse(h, reverse_mask), h->n_cus, st));
-    hipLaunchKernelGGL(k_host_pack, dim3(1), dim3(256), 0, st, d, h->p, hd, L);
+    hipLaunchKernelGGL(k_host_pack, dim3(1), dim3(256), 0, st, d, h->p, hd, L, py_out ? (uint32_t*)(hd + L.py_out) : nullptr,
+                       np_out ? (uint32_t*)(hd + L.np_out) : nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // the only wait of the call: every output already lies in host memory
     if (rewards && actions) memcpy(rewards, hh + L.rw64, (size_t)d.N * 8);
