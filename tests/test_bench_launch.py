@@ -111,3 +111,23 @@ def test_bench_rollout_gpus_2_runs_the_two_rank_iteration():
     assert "DRY RUN" in line["metric"]
     r = _run("bench_rollout.py", "--gpus", "2", env=dict(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_cpu_baseline_block_reports_one_core_the_box_share_and_all_usable_cores():
+    """the C oracle timed on one core and on all host cores the process may use (affinity mask capped by the cgroup's CPU
+    quota), core counts and CPU model stated; the per-env Python / NumPy restatement on one core beside it."""
+    import importlib
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    pkg = importlib.import_module("marl-ctf-development_amd")
+    kw = bench.WORKLOADS["arena"][1](pkg)
+    out = bench.cpu_baseline(pkg, kw, budget_s=0.6)
+    assert out["kind"] == "port" and out["unit"] == "env-steps/s" and out["value"] > 0 and out["single_core_value"] > 0
+    usable = min(len(os.sched_getaffinity(0)), bench._cpu_quota() or 1 << 30)
+    assert out["cores"] == min(len(os.sched_getaffinity(0)), 16) and out["all_cores"] == usable
+    assert out["all_cores_value"] and out["all_cores_value"] > 0 and out["all_cores_sample"]
+    assert out["host_cpu"]["logical_cpus"] == os.cpu_count() and out["host_cpu"]["model"]
+    assert out["python_numpy_1core"]["cores"] == 1 and out["python_numpy_1core"]["value"] > 0
+    assert bench._cpu_quota() is None or bench._cpu_quota() >= 1
