@@ -66,9 +66,22 @@ def run(envs=16384, steps=16, policy="native", dtype="bf16", update=True, update
     if os.environ.get("CTF_ROLLOUT_OVERLAP") == "1":  # A/B only: the opponent's conv front on a second stream (measured slower)
         col.overlap_teams = True
     warm = pkg.BatchedRolloutCollector(vec, min(steps, 4), 0) if steps > 16 else col
-    warm.collect(*nets)  # warm-up (kernel selection, buffer placement)
+    # Warm-up: kernel selection, buffer placement — and the clocks.  A process that times its first or second rollout reads 15-21 M
+    # env-steps/s where the ninth reads 31 M (round 5: three of four cold standalone runs; inside bench.py, after 20 s of env work, the
+    # same call reads 31 M every time).  So: warm-up rollouts until two in a row take the same time within 3 % (at most twelve).
+    prev, n_warm = None, 0
+    while n_warm < 12:
+        torch.cuda.synchronize(dev)
+        tw = time.perf_counter()
+        warm.collect(*nets)
+        torch.cuda.synchronize(dev)
+        tw = time.perf_counter() - tw
+        n_warm += 1
+        if prev is not None and abs(tw - prev) <= 0.03 * prev:
+            break
+        prev = tw
     del warm
-    log("warm-up rollout done")
+    log(f"warm-up done ({n_warm} rollouts)")
     _sync(torch, dist, dev)
     t0 = time.perf_counter()
     out = col.collect(*nets)
