@@ -183,13 +183,15 @@ class VecGridworldCtf:
         # Once a buffer of the good cluster is in hand the search goes on for its BEST members — the cluster itself spans render / fill
         # 1.04-1.10 (0.246-0.264 ms on the arena; round 5: one box's two runs kept 0.2614 and 0.2497 = 199 and 207 M env-steps/s) and a
         # candidate costs 1.5 ms — until one is good enough, the tries are used up, or `placement_seconds` (default 1.0;
-        # CTF_PLACEMENT_SECONDS) have gone by (four times that when no buffer of the good cluster has turned up at all).  (Round 3's rule — eight more tries — found a second good one 4 times in 10.)
+        # CTF_PLACEMENT_SECONDS) have gone by (ten times that while no buffer of the fast kind has turned up at all).  (Round 3's rule — eight more tries — found a second good one 4 times in 10.)
         for _ in range(tries - 1):
             if best_ms <= good_enough * fill_ms:
                 break
             elapsed = time.perf_counter() - t0
-            if (best_ms <= 0.93 * max(times) and elapsed > self._placement_seconds) or elapsed > 4 * self._placement_seconds:
-                break  # (the second bound: a box whose allocations take 50 ms each and are all of one kind)
+            in_hand = best_ms <= 0.93 * max(times) or best_ms <= 1.12 * fill_ms  # a buffer of the fast kind, by either measure
+            if (in_hand and elapsed > self._placement_seconds) or elapsed > 10 * self._placement_seconds:
+                break  # (the second bound: a box that hands out slow allocations only — one in six to thirteen fresh boxes; at 50 ms a
+                       # candidate ten seconds are ~200 tries, enough where one allocation in fifty is fast)
             try:
                 cand = torch.empty_like(best)
             except torch.cuda.OutOfMemoryError:
