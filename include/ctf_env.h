@@ -201,8 +201,8 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  * allocation's physical backing, independent from one allocation to the next even after a free.  A caller that cares allocates a
  * candidate, times ctf_observe into it against a plain fill of the same bytes (the fill does not depend on the kind: render / fill
  * <= 1.10 is the fast kind, >= 1.2 the slow one), frees it if it is slow and tries again.  The Python facade does exactly that on first use of its
- * observation buffer: knobs placement_tries (default 256 candidates, CTF_PLACEMENT_TRIES), CTF_PLACEMENT_SECONDS (default 1.0: once a
- * buffer of the fast kind is in hand the search for a better one ends after this long; ten times this while none has turned up) and placement_gib (default 16: the cap
+ * observation buffer: knobs placement_tries (default 256 candidates, CTF_PLACEMENT_TRIES), CTF_PLACEMENT_SECONDS (default 3.0: once a
+ * buffer of the fast kind is in hand the search for a better one ends after this long; ten seconds while none has turned up) and placement_gib (default 16: the cap
  * on what the search may HOLD — it holds two buffers, the candidate and the best so far; CTF_PLACEMENT_GIB), tune_placement=False
  * to switch it off; VecGridworldCtf.placement reports kind, ratio, candidates tried, bytes held and the time it took. */
 #define CTF_REVERSE_DEFAULT 0xFFFFFFFFu
