@@ -182,14 +182,14 @@ class VecGridworldCtf:
         # Once a buffer of the good cluster is in hand the search goes on for its BEST members — the cluster itself spans render / fill
         # 1.04-1.10 (0.246-0.264 ms on the arena; round 5: one box's two runs kept 0.2614 and 0.2497 = 199 and 207 M env-steps/s) and a
         # candidate costs 1.5 ms — until one is good enough, the tries are used up, or `placement_seconds` (default 3.0;
-        # CTF_PLACEMENT_SECONDS) have gone by (ten seconds while no buffer of the fast kind has turned up at all).  (Round 3's rule — eight more tries — found a second good one 4 times in 10.)
+        # CTF_PLACEMENT_SECONDS) have gone by (3.3 times that, i.e. ten seconds by default, while no buffer of the fast kind has turned up at all).  (Round 3's rule — eight more tries — found a second good one 4 times in 10.)
         for _ in range(tries - 1):
             if best_ms <= good_enough * fill_ms:
                 break
             elapsed = time.perf_counter() - t0
             in_hand = best_ms <= 1.12 * fill_ms  # a buffer of the fast kind (the relative test of round 3 — 7 % under the slowest seen —
                                                  # misfires on one outlier: a slow-only box stopped at 1.19 after 3.7 s)
-            if (in_hand and elapsed > self._placement_seconds) or elapsed > max(10.0, self._placement_seconds):
+            if (in_hand and elapsed > self._placement_seconds) or elapsed > min(10.0, 3.3 * self._placement_seconds):
                 break  # (the second bound: a box that hands out slow allocations only — one in six to thirteen fresh boxes; at 50 ms a
                        # candidate ten seconds are ~200 tries, enough where one allocation in fifty is fast)
             try:

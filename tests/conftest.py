@@ -8,6 +8,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the tests check results, not speed: the timed search for a fast observation buffer (VecGridworldCtf._tune_obs_placement: up to
+    # 3 s per 65 536-env batch, 10 s on a box that hands out slow allocations only) is cut short for the suite
+    os.environ.setdefault("CTF_PLACEMENT_SECONDS", "0.2")
 
 
 def pytest_sessionstart(session):
