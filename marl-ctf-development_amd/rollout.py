@@ -207,6 +207,19 @@ class BatchedRolloutCollector:
         if rc != 0:
             raise _abi.CtfLibraryError("ctf_rollout_store_step: " + (sa["lib"].ctf_policy_last_error() or b"").decode())
 
+    def preallocate(self, agent, opponent):
+        """The observation part of the rollout buffer (29 GB of codes for 65 536 envs x 500 steps), allocated on the first collect
+        otherwise — a hipMalloc of tens of GB takes 0.1-1.5 s: a caller that times its first ``collect`` calls this before.  -> whether
+        the collector runs in compact mode for these two policies."""
+        torch, vec = self.torch, self.vec
+        use_codes = self.use_codes(agent, opponent)
+        E, S, g = vec.n_envs, self.T * self.A, vec.GRID_SIZE
+        if use_codes and self.grid_codes is None:
+            self.grid_codes = torch.zeros((S, E, g, g), dtype=torch.uint8, device=vec.device)
+        if not use_codes and self.grid_states is None:
+            self.grid_states = torch.zeros((S, E, vec.N_CHANNELS, g, g), dtype=self.obs_dtype, device=vec.device)
+        return use_codes
+
     def collect(self, agent, opponent, reset=True, handoff=None, handoff_chunk=16):
         """-> dict with the tensors ``get_single_rollout`` returns, each with an env axis after the slot axis.  In compact
         mode ``grid_codes`` / ``next_grid_codes`` stand in for ``grid_states`` / ``next_grid_state``.
@@ -217,12 +230,8 @@ class BatchedRolloutCollector:
         ``"global"`` the same tensors for ALL ranks' envs in global env order ([S, world * E, ...]) plus the gathered
         ``next_*`` tensors.  Compact mode only (the one-hot planes are 14x the bytes; a learner expands codes per minibatch)."""
         torch, vec, A = self.torch, self.vec, self.A
-        use_codes = self.use_codes(agent, opponent)
+        use_codes = self.preallocate(agent, opponent)
         E, S, g = vec.n_envs, self.T * self.A, vec.GRID_SIZE
-        if use_codes and self.grid_codes is None:
-            self.grid_codes = torch.zeros((S, E, g, g), dtype=torch.uint8, device=vec.device)
-        if not use_codes and self.grid_states is None:
-            self.grid_states = torch.zeros((S, E, vec.N_CHANNELS, g, g), dtype=self.obs_dtype, device=vec.device)
         if handoff is not None and handoff.with_observations and not use_codes:
             raise ValueError("the rollout hand-off carries observations in compact form only (use policies with act_from_codes)")
         local = dict(rewards=self.rewards, logprobs=self.logprobs, values=self.values, actions=self.actions,
