@@ -13,6 +13,9 @@
  *     the library never allocates or frees I/O buffers;
  *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream); calls that take a
  *     stream only enqueue work on it and return;
+ *   - ctf_step, ctf_observe, ctf_observe_codes, ctf_step_observe and ctf_reset are kernel launches and nothing else (no
+ *     allocation, no copy, no synchronisation, no host-side state that moves from call to call), so a caller may capture them
+ *     into a hipGraph on `stream` and replay it: every replay is the next step (tests/test_gpu_hipgraph.py);
  *   - return value 0 = OK, negative = error (see CTF_E_*); `ctf_last_error()` has the text;
  *   - a handle is not thread-safe; distinct handles are independent (one per GPU / shard).
  */

@@ -17,7 +17,7 @@
 
 extern "C" hipError_t ctf_launch_seed(const DevCfg&, const DevPtrs&, const uint64_t*, const uint64_t*, hipStream_t);
 extern "C" hipError_t ctf_launch_reset(const DevCfg&, const DevPtrs&, const uint8_t*, int, hipStream_t);
-extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t ctf_launch_step(const DevCfg&, const DevPtrs&, const int8_t*, float*, double*, uint8_t*, uint32_t, int, hipStream_t);
 extern "C" int ctf_step_blocks(const DevCfg&);
 extern "C" int ctf_observe_uses_tiles(const DevCfg&, const uint8_t*);
 extern "C" hipError_t ctf_launch_observe(const DevCfg&, const DevPtrs&, uint8_t*, uint16_t*, uint32_t, int, hipStream_t);
@@ -38,7 +38,6 @@ struct ctf_env {
     int n_cus;
     uint64_t* seed_scratch;  // device, 2*E u64
     uint32_t* rng_scratch;   // device, 2 x 625 u32: one env's two generators in the standard form (ctf_set/get_rng_state)
-    uint32_t step_phase;     // counts the step launches (k_step's tail blocks: which share of the stale rings this launch takes)
     // ctf_host_step (n_envs == 1): one pinned, device-mapped host block (allocated on first use) that the kernels read and write directly
     uint8_t* hio_dev;   // the DEVICE address of that block (hipHostGetDevicePointer)
     uint8_t* hio_host;  // its host address
@@ -89,12 +88,6 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(CTF_E_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-// After a seed / state import every ring is in place (k_rng_refill(init)): nothing is left over for a tail block.
-static hipError_t rng_fresh(ctf_env* h, hipStream_t) {
-    h->step_phase = 0;
-    return hipSuccess;
-}
-
 // remembers and restores the caller's current device
 struct DeviceGuard {
     int prev = -1;
@@ -116,7 +109,7 @@ static void free_all(ctf_env* h) {
     (void)hipFree(h->p.grid); (void)hipFree(h->p.rec); (void)hipFree(h->p.mt_py); (void)hipFree(h->p.mt_np);
     (void)hipFree(h->p.rngpos); (void)hipFree(h->p.metrics); (void)hipFree(h->p.vis); (void)hipFree(h->p.vislog);
     (void)hipFree((void*)h->p.init_grid); (void)hipFree((void*)h->p.meta_lut); (void)hipFree(h->p.status); (void)hipFree(h->seed_scratch);
-    (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch); (void)hipFree(h->p.rngready);
+    (void)hipFree(h->p.rngctr); (void)hipFree(h->rng_scratch); (void)hipFree(h->p.rngready); (void)hipFree(h->p.rngage);
     (void)hipFree(h->p.py_top); (void)hipFree(h->p.np_hit); (void)hipFree(h->p.np_nib);
     if (h->hio_host) (void)hipHostFree(h->hio_host);
     delete h;
@@ -138,7 +131,6 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     memset(&h->p, 0, sizeof(h->p));
     h->seed_scratch = nullptr;
     h->rng_scratch = nullptr;
-    h->step_phase = 0;
     h->hio_dev = nullptr;
     h->hio_host = nullptr;
     h->cfg = *cfg; h->d = d; h->device = device_id;
@@ -159,6 +151,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     ALLOC(h->p.np_nib, E * 2 * CTF_NB_DW * 4);
     ALLOC(h->p.rngpos, E * 2 * 4);
     ALLOC(h->p.rngready, E * 2);
+    ALLOC(h->p.rngage, E * 2);
     ALLOC(h->p.rngctr, (d.rng_mode == CTF_RNG_COUNTER ? E * 6 : 1) * 8);
     ALLOC(h->rng_scratch, 2 * (CTF_MT_N + 1) * 4);
     ALLOC(h->p.metrics, met_elems * 4);
@@ -183,7 +176,7 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     hipError_t e5 = hipMemset(h->seed_scratch, 0, E * 2 * 8);
     hipError_t e6 = ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, nullptr);
     if (e6 == hipSuccess) e6 = ctf_launch_rng_refill(h->d, h->p, 0, n_envs, 1, nullptr);
-    if (e6 == hipSuccess) e6 = rng_fresh(h, nullptr);
+    if (e6 == hipSuccess) e6 = hipMemset(h->p.rngage, 0, E * 2);  // (a seed / state import leaves every ring in place: the ages go back to 0 by themselves, tail_block)
     hipError_t e7 = hipDeviceSynchronize();
     if (e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
         const hipError_t bad = e4 != hipSuccess ? e4 : e5 != hipSuccess ? e5 : e6 != hipSuccess ? e6 : e7;
@@ -221,7 +214,6 @@ extern "C" int ctf_seed(ctf_env* h, const uint64_t* py_seeds, const uint64_t* np
     HIP_TRY(hipMemcpyAsync(h->seed_scratch + E, np_seeds, E * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctf_launch_seed(h->d, h->p, h->seed_scratch, h->seed_scratch + E, st));
     HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, st));  // the blocks after the seeded ones, and all digests
-    HIP_TRY(rng_fresh(h, st));
     HIP_TRY(hipStreamSynchronize(st));  // the host arrays are the caller's; do not outlive the call
     return CTF_OK;
 }
@@ -253,7 +245,6 @@ extern "C" int ctf_set_rng_state(ctf_env* h, int32_t e, const uint32_t* py, cons
         // every ring of every env is brought up to date (envs other than e: whatever the last step left for the next launch's tail)
         HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 0, nullptr));
         HIP_TRY(ctf_launch_rng_refill(h->d, h->p, e, 1, 1, nullptr));  // (a stream of env e that was not handed over is simply redone)
-        HIP_TRY(rng_fresh(h, nullptr));
         HIP_TRY(hipDeviceSynchronize());
     }
     return CTF_OK;
@@ -282,7 +273,6 @@ extern "C" int ctf_set_rng_states(ctf_env* h, const uint32_t* py_dev, const uint
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_import_rng(h->d, h->p, py_dev, np_dev, 0, h->d.n_envs, (hipStream_t)stream));
     HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, (hipStream_t)stream));
-    HIP_TRY(rng_fresh(h, (hipStream_t)stream));
     return CTF_OK;
 }
 
@@ -309,7 +299,6 @@ extern "C" int ctf_set_rng_counters(ctf_env* h, const uint64_t* counters_dev, vo
     DeviceGuard guard(h->device);
     HIP_TRY(ctf_launch_set_counters(h->d, h->p, (const unsigned long long*)counters_dev, (hipStream_t)stream));
     HIP_TRY(ctf_launch_rng_refill(h->d, h->p, 0, h->d.n_envs, 1, (hipStream_t)stream));
-    HIP_TRY(rng_fresh(h, (hipStream_t)stream));
     return CTF_OK;
 }
 
@@ -323,7 +312,7 @@ extern "C" int ctf_reset(ctf_env* h, const uint8_t* mask_dev, void* stream) {
 extern "C" int ctf_step(ctf_env* h, const int8_t* actions, float* rw32, double* rw64, uint8_t* done, uint32_t flags, void* stream) {
     if (!h || !actions) return fail(CTF_E_INVALID, "null argument");
     DeviceGuard guard(h->device);
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, 1, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, 1, (hipStream_t)stream));
     return CTF_OK;
 }
 
@@ -359,7 +348,7 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
     // (The ring regeneration rides at the tail of the step launch.  Running it as a launch of its own on a second stream, beside
     // the render, was built and measured in round 3: the render lost more than the step kernel gained — 189-191 M against 198 M
     // env-steps/s, profiles/r03_side_stream_ablation.md.)
-    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, h->step_phase++, 1, (hipStream_t)stream));
+    HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, 1, (hipStream_t)stream));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;
@@ -526,11 +515,10 @@ extern "C" int ctf_host_step(ctf_env* h, const int8_t* actions, const uint32_t* 
         HIP_TRY(ctf_launch_import_rng(d, h->p, py_in ? (const uint32_t*)(hd + L.py_in) : nullptr,
                                       np_in ? (const uint32_t*)(hd + L.np_in) : nullptr, 0, 1, st));
         HIP_TRY(ctf_launch_rng_refill(d, h->p, 0, 1, 1, st));
-        HIP_TRY(rng_fresh(h, st));
     }
     if (actions)
         HIP_TRY(ctf_launch_step(d, h->p, (const int8_t*)(hd + L.actions), nullptr, (double*)(hd + L.rw64), hd + L.done_status, flags,
-                                h->step_phase++, 1, st));
+                                1, st));
     if (obs || meta)
         HIP_TRY(ctf_launch_observe(d, h->p, obs ? hd + L.obs : nullptr, meta ? (uint16_t*)(hd + L.meta) : nullptr,
                                    resolve_reverse(h, reverse_mask), h->n_cus, st));

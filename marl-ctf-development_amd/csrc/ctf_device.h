@@ -14,6 +14,7 @@
 //   np_nib u32 [E][2][92]     ... and the low 4 bits of the tempered word (randint over the spawn window); + mirrors
 //   rngpos u32 [E][2]         per stream: position 0..624 in the current ring | current ring << 16
 //   rngready u8 [E][2]        per stream: 1 = the other ring is in place; 2 + r = ring r is stale and waits for its regeneration
+//   rngage u8 [E][2]          per stream: step launches a stale ring has waited so far (k_step's tail blocks: theirs alone)
 //   rngctr u64 [E][6]         counter mode only (cfg.rng_mode == 1): stream index of word 0 of ring 0 / ring 1 (py), of ring 0 / 1 (np), seeds (py, np)
 //   metric i32 [E][13][N]     agent-level counters (only when log_metrics)
 //   vislog u16 [512][E][N]    visitation LOG: entry (step % 512) = the cell of every agent after that step; the
@@ -52,8 +53,8 @@ struct DevCfg {
     int32_t rng_refill_every;       // 1: rings are regenerated at the tail of the next step launch (default); 0: never (tests: the
                                     // step kernel's safety net does all the work)
     int32_t rng_safe_ahead;         // words: a step that starts this far (or further) before the end of its block needs no other ring
-    int32_t rng_spread;             // a stale ring is regenerated within this many launches: a burst of them (the envs' positions
-                                    // move in step) is spread over as many launches
+    int32_t rng_spread;             // a stale ring is regenerated within this many launches of being seen: a burst of them (the
+                                    // envs' positions move in step) is spread over as many launches by the rings' ages (rngage)
     int32_t n_cus;                  // compute units of the device (launch shapes)
     // np.random.rand() < TAG_PROBABILITY on the 53-bit integer x = (a >> 5) * 2^26 + (b >> 6): x < tag_thr, split at bit 26
     uint32_t tag_th, tag_tl;
@@ -92,6 +93,7 @@ struct DevPtrs {
     uint32_t* mt_np;
     uint32_t* rngpos;
     uint8_t* rngready;
+    uint8_t* rngage;
     unsigned long long* rngctr;  // counter mode: u64 [E][6] = stream index of word 0 of each ring (py 0, py 1, np 0, np 1), stream seeds (py, np)
     uint32_t* py_top;
     uint32_t* np_hit;

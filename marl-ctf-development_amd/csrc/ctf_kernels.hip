@@ -373,17 +373,28 @@ extern "C" int ctf_debug_step_trace(unsigned long long* host_out) {
 #endif
 
 // A TAIL block of k_step: regenerates rings whose consumers have moved on (rngready says
-// which).  It looks after STEP_TAIL_PAIRS (env, stream) pairs; a stale ring of env e is taken by the launch with
-// (e + phase) % rng_spread == 0, because the envs' stream positions move in step (every env draws the same words per step, give
-// or take a respawn): most of them leave their block in the same step, and that burst is spread over rng_spread launches —
-// always before the ring is needed.  A tail block touches nothing a step block reads: an env whose ring is stale stands at the
-// head of its new block and looks at neither the other ring nor its mirror.
-__device__ __forceinline__ void tail_block(const DevCfg& cfg, const DevPtrs& p, int tb, uint32_t phase, int lane, uint32_t* lds) {
+// which).  It looks after STEP_TAIL_PAIRS (env, stream) pairs; a stale ring of env e is taken by the launch that finds it at
+// the age (launches waited so far) with (e + age) % rng_spread == 0, because the envs' stream positions move in step (every env
+// draws the same words per step, give or take a respawn): most of them leave their block in the same step, and that burst is
+// spread over rng_spread launches — always before the ring is needed.  The ages live in device memory (rngage, written by the
+// pair's tail block only), not in a launch argument: a launch is the same whichever step it is, so a caller may capture
+// ctf_step / ctf_step_observe into a hipGraph and replay it.  A tail block touches nothing a step block reads: an env whose ring
+// is stale stands at the head of its new block and looks at neither the other ring nor its mirror.
+__device__ __forceinline__ void tail_block(const DevCfg& cfg, const DevPtrs& p, int tb, int lane, uint32_t* lds) {
     const int first = tb * STEP_TAIL_PAIRS;
-    uint32_t flag = 1;
-    if (lane < STEP_TAIL_PAIRS && first + lane < 2 * cfg.n_envs) flag = p.rngready[first + lane];
-    const int spread = cfg.rng_spread;
-    unsigned long long work = __ballot(flag >= 2u && (uint32_t)(((first + lane) >> 1) + (int)phase) % (uint32_t)spread == 0u);
+    const bool mine = lane < STEP_TAIL_PAIRS && first + lane < 2 * cfg.n_envs;
+    uint32_t flag = 1, age = 0;
+    if (mine) {
+        flag = p.rngready[first + lane];
+        age = p.rngage[first + lane];
+    }
+    const uint32_t spread = (uint32_t)cfg.rng_spread;
+    const bool take = flag >= 2u && (((uint32_t)((first + lane) >> 1) + age) % spread == 0u || age >= spread);
+    {   // a ring that goes on waiting is a launch older; everything else is new again
+        const uint32_t older = (flag >= 2u && !take) ? age + 1u : 0u;
+        if (mine && older != age) p.rngage[first + lane] = (uint8_t)older;
+    }
+    unsigned long long work = __ballot(take);
     STEP_STAMP(0);
     int n_done = 0;
     if (work) {  // uniform
@@ -415,7 +426,7 @@ __device__ __forceinline__ void tail_block(const DevCfg& cfg, const DevPtrs& p, 
 template <bool METRICS, int W>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restrict__ rw32, double* __restrict__ rw64,
-       uint8_t* __restrict__ done_out, uint32_t flags, uint32_t phase, int n_step_blocks) {
+       uint8_t* __restrict__ done_out, uint32_t flags, int n_step_blocks) {
     constexpr int EPW = WAVE / W;  // envs per wave
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ uint32_t lds[];
@@ -427,7 +438,7 @@ k_step(DevCfg cfg, DevPtrs p, const int8_t* __restrict__ actions, float* __restr
     const int sb = STEP_TAIL_FIRST ? (int)blockIdx.x - n_tail_blocks : (int)blockIdx.x;  // this step block's index
     if (STEP_TAIL_FIRST ? sb < 0 : sb >= n_step_blocks) {
         // ---- a TAIL block (see tail_block): these start as step blocks retire — the LDS is full until then
-        tail_block(cfg, p, STEP_TAIL_FIRST ? (int)blockIdx.x : sb - n_step_blocks, phase, lane, lds);
+        tail_block(cfg, p, STEP_TAIL_FIRST ? (int)blockIdx.x : sb - n_step_blocks, lane, lds);
         return;
     }
     STEP_STAMP(0);
@@ -1340,22 +1351,22 @@ extern "C" hipError_t ctf_launch_reset(const DevCfg& cfg, const DevPtrs& p, cons
 }
 template <bool METRICS, int W>
 static void launch_step_w(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64, uint8_t* done,
-                          uint32_t flags, uint32_t phase, bool with_tail, hipStream_t st) {
+                          uint32_t flags, bool with_tail, hipStream_t st) {
     constexpr int EPW = WAVE / W;
     const int nstep = (cfg.n_envs + EPW - 1) / EPW;
     const int ntail = with_tail ? (2 * cfg.n_envs + STEP_TAIL_PAIRS - 1) / STEP_TAIL_PAIRS : 0;
     const dim3 grid(nstep + ntail), block(WAVE);
     size_t sh = (size_t)EPW * step_slot_bytes(cfg.GS, cfg.RS, cfg.N, METRICS);
     if (sh < 2 * CTF_MT_N * 4) sh = 2 * CTF_MT_N * 4;  // a tail block stages two rings
-    hipLaunchKernelGGL((k_step<METRICS, W>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags, phase, nstep);
+    hipLaunchKernelGGL((k_step<METRICS, W>), grid, block, sh, st, cfg, p, actions, rw32, rw64, done, flags, nstep);
 }
 template <bool METRICS>
 static void launch_step_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                          uint8_t* done, uint32_t flags, uint32_t phase, bool with_tail, hipStream_t st) {
-    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
-    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
-    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
-    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, phase, with_tail, st);
+                          uint8_t* done, uint32_t flags, bool with_tail, hipStream_t st) {
+    if (w <= 1) launch_step_w<METRICS, 1>(cfg, p, actions, rw32, rw64, done, flags, with_tail, st);
+    else if (w == 2) launch_step_w<METRICS, 2>(cfg, p, actions, rw32, rw64, done, flags, with_tail, st);
+    else if (w == 4) launch_step_w<METRICS, 4>(cfg, p, actions, rw32, rw64, done, flags, with_tail, st);
+    else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, with_tail, st);
 }
 // lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn — and more
 // (up to 8) for a batch too small to give every SIMD of the chip a wave: fewer envs per wave then, i.e. a shorter divergent
@@ -1367,14 +1378,14 @@ static int step_lanes(const DevCfg& cfg) {
     if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling / test knob (CTF_STEP_W)
     return w;
 }
-// phase: counts the step launches (which share of a burst of stale rings this launch's tail blocks take); with_tail: the ring
-// regeneration rides at the tail of this launch
+// with_tail: the ring regeneration rides at the tail of this launch.  Nothing in the launch depends on how many went before it
+// (see tail_block), so a captured launch can be replayed.
 extern "C" hipError_t ctf_launch_step(const DevCfg& cfg, const DevPtrs& p, const int8_t* actions, float* rw32, double* rw64,
-                                      uint8_t* done, uint32_t flags, uint32_t phase, int with_tail, hipStream_t st) {
+                                      uint8_t* done, uint32_t flags, int with_tail, hipStream_t st) {
     const int w = step_lanes(cfg);
     const bool tail = with_tail && cfg.rng_refill_every;
-    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, phase, tail, st);
-    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, phase, tail, st);
+    if (cfg.log_metrics) launch_step_m<true>(w, cfg, p, actions, rw32, rw64, done, flags, tail, st);
+    else launch_step_m<false>(w, cfg, p, actions, rw32, rw64, done, flags, tail, st);
     return hipGetLastError();
 }
 extern "C" int ctf_step_blocks(const DevCfg& cfg) { return (cfg.n_envs + WAVE / step_lanes(cfg) - 1) / (WAVE / step_lanes(cfg)); }

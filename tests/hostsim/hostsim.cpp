@@ -30,14 +30,13 @@ static int fail(int code, const char* fmt, ...) {
 struct hs_env {
     DevCfg d;
     DevPtrs p;
-    std::vector<uint8_t> grid, rec, init_grid, rngready;
+    std::vector<uint8_t> grid, rec, init_grid, rngready, rngage;
     std::vector<uint32_t> mt_py, mt_np, py_top, np_hit, np_nib, rngpos, vis, status;
     std::vector<unsigned long long> rngctr;
     std::vector<int32_t> metrics;
     std::vector<uint16_t> vislog;
     std::vector<uint32_t> lds;
     int refill_every;
-    uint32_t phase;  // counts the steps (ctf_abi.hip: step_phase)
 };
 
 static void stream_of(hs_env* h, int e, int stream, StreamFull* st) { *st = stream_full(h->d, h->p, e, stream); }
@@ -93,13 +92,16 @@ static void step_all(hs_env* h, const int8_t* actions, float* rw32, double* rw64
             for (int w = 0; w < CTF_N_METRICS * N; w++) h->metrics[(size_t)e * CTF_N_METRICS * N + w] += dl[w];
         }
     }
-    // the launch's TAIL blocks: stale rings are regenerated, each env's in its share of the launches (k_step) — after this step's
+    // the launch's TAIL blocks: stale rings are regenerated, each env's at its own age (k_step's tail_block) — after this step's
     // groups have run, which is the latest the real launch gets to them
     if (h->refill_every)
         for (int e = 0; e < d.n_envs; e++)
-            for (int k = 0; k < 2; k++)
-                if (h->p.rngready[2 * e + k] >= 2 && (uint32_t)(e + (int)h->phase) % (uint32_t)d.rng_spread == 0) refill_one(h, e, k);
-    h->phase++;
+            for (int k = 0; k < 2; k++) {
+                const uint32_t flag = h->p.rngready[2 * e + k], age = h->p.rngage[2 * e + k], spread = (uint32_t)d.rng_spread;
+                const bool take = flag >= 2 && (((uint32_t)e + age) % spread == 0 || age >= spread);
+                h->p.rngage[2 * e + k] = (uint8_t)((flag >= 2 && !take) ? age + 1 : 0);
+                if (take) refill_one(h, e, k);
+            }
 }
 
 extern "C" {
@@ -123,8 +125,8 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
     h->np_nib.assign(E * 2 * CTF_NB_DW, 0xA5A5A5A5u);
     h->rngpos.assign(E * 2, 0);
     h->rngready.assign(E * 2, 0);
+    h->rngage.assign(E * 2, 0);
     h->refill_every = h->d.rng_refill_every;
-    h->phase = 0;
     h->rngctr.assign(E * 6, 0);
     h->metrics.assign(E * CTF_N_METRICS * d.N, 0);
     h->vis.assign(E * d.N * d.GS, 0);
@@ -133,7 +135,7 @@ hs_env* hs_create(const ctf_config* cfg, int32_t n_envs) {
     h->lds.assign((size_t)step_slot_bytes(d.GS, d.RS, d.N, true) / 4 + 4, 0);
     h->p.grid = h->grid.data(); h->p.rec = h->rec.data();
     h->p.mt_py = h->mt_py.data(); h->p.mt_np = h->mt_np.data();
-    h->p.rngpos = h->rngpos.data(); h->p.rngctr = h->rngctr.data(); h->p.rngready = h->rngready.data();
+    h->p.rngpos = h->rngpos.data(); h->p.rngctr = h->rngctr.data(); h->p.rngready = h->rngready.data(); h->p.rngage = h->rngage.data();
     h->p.py_top = h->py_top.data(); h->p.np_hit = h->np_hit.data(); h->p.np_nib = h->np_nib.data();
     h->p.metrics = h->metrics.data(); h->p.vis = h->vis.data(); h->p.vislog = h->vislog.data();
     h->p.init_grid = h->init_grid.data(); h->p.meta_lut = nullptr; h->p.status = h->status.data();
