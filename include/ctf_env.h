@@ -197,13 +197,15 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  *   reverse_mask bit i = reverse_grid for agent i; CTF_REVERSE_DEFAULT = (team(i) == 1), the value
  *                every caller in the reference passes (ppo.py:69,87; utils.py:535)
  * One launch: k_observe_tiles (one wave per 8 KiB of the flat buffer) when an env's block is a multiple of 16 bytes and at
- * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way.
+ * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way.  The tile
+ * kernel's stores carry the nontemporal hint (the observations pass by the caches, which keep the env state for the next step;
+ * CTF_OBS_NT=0 at ctf_create: plain stores) — a consumer reads them from HBM either way: they are far larger than any cache.
  *
  * PLACEMENT of obs_dev (the caller's buffer, so the caller's business): on MI355X roughly one hipMalloc allocation
- * of > 1 GiB in ten is of a kind this launch streams into at 0.82 of the HBM peak, the others cost it 15-20 % — a property of the
+ * of > 1 GiB in ten is of a kind this launch streams into at 0.87 of the HBM peak, the others cost it 15-20 % — a property of the
  * allocation's physical backing, independent from one allocation to the next even after a free.  A caller that cares allocates a
  * candidate, times ctf_observe into it against a plain fill of the same bytes (the fill does not depend on the kind: render / fill
- * <= 1.10 is the fast kind, >= 1.2 the slow one), frees it if it is slow and tries again.  The Python facade does exactly that on first use of its
+ * <= 1.08 is the fast kind, >= 1.15 the slow one), frees it if it is slow and tries again.  The Python facade does exactly that on first use of its
  * observation buffer: knobs placement_tries (default 256 candidates, CTF_PLACEMENT_TRIES), CTF_PLACEMENT_SECONDS (default 3.0: once a
  * buffer of the fast kind is in hand the search for a better one ends after this long; ten seconds while none has turned up) and placement_gib (default 16: the cap
  * on what the search may HOLD — it holds two buffers, the candidate and the best so far; CTF_PLACEMENT_GIB), tune_placement=False

@@ -172,6 +172,11 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
             if (v >= 1 && v <= d->rng_spread) d->rng_spread = v;
         }
     }
+    // the tile render's stores carry the nontemporal hint: 1.65 GB of observations per launch then pass by the caches instead of
+    // sweeping the 88 MB of grids, records and digest windows out of them that the next k_step (and the render itself) reads —
+    // k_step 0.067 -> 0.059 ms, the render 0.251 -> 0.248 ms on the same buffer (profiles/r05_render_nontemporal.md).  CTF_OBS_NT=0: plain.
+    d->obs_store_nt = 1;
+    if (const char* ov = getenv("CTF_OBS_NT")) d->obs_store_nt = atoi(ov) != 0;
     if (const char* ov = getenv("CTF_STEP_W")) {
         const int w = atoi(ov);
         if (w == 1 || w == 2 || w == 4 || w == 8) d->step_lanes_override = w;

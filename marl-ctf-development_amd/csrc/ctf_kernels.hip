@@ -958,7 +958,8 @@ __host__ __device__ inline int tiles_wave_bytes(int RS, int N, int M) {
     return OBS_TILE / 8 + RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
 }
 
-__global__ void __launch_bounds__(256) k_observe_tiles(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs, uint16_t* __restrict__ meta,
+template <int STORE_NT>  // 1 (default, ctf_derive.h): the tile's stores carry the nontemporal hint and pass by the caches
+__global__ void __launch_bounds__(CTF_OBS_TILE_WPB * 64) k_observe_tiles(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs, uint16_t* __restrict__ meta,
                                                        uint32_t reverse_mask, uint32_t xcd_map) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1077,7 +1078,10 @@ __global__ void __launch_bounds__(256) k_observe_tiles(DevCfg cfg, DevPtrs p, ui
         for (int u = 0; u < OBS_TILE / 1024; u++) {
             const int k = u * WAVE + lane;
             const u32x4_t v = {expand4(h[u], 0), expand4(h[u], 1), expand4(h[u], 2), expand4(h[u], 3)};
-            if (k < nchunk && !(OBS_ABLATE & 2)) *(u32x4_t*)(out + ((size_t)k << 4)) = v;
+            if (k < nchunk && !(OBS_ABLATE & 2)) {
+                if (STORE_NT) __builtin_nontemporal_store(v, (u32x4_t*)(out + ((size_t)k << 4)));
+                else *(u32x4_t*)(out + ((size_t)k << 4)) = v;
+            }
         }
     }
     // ---- metadata rows of the env whose block starts in this tile (behind the stores: off the stream's path)
@@ -1369,12 +1373,13 @@ static void launch_step_m(int w, const DevCfg& cfg, const DevPtrs& p, const int8
     else launch_step_w<METRICS, 8>(cfg, p, actions, rw32, rw64, done, flags, with_tail, st);
 }
 // lanes per env: the power of two that covers the larger opponents list (<= 8), so one tag pass per agent turn — and more
-// (up to 8) for a batch too small to give every SIMD of the chip a wave: fewer envs per wave then, i.e. a shorter divergent
-// chain per wave (0_the_split at 4 096 envs: 2 -> 8 lanes, 0.0312 -> 0.0280 ms per env-step).  Results do not depend on it.
+// (up to 8) as long as the waves that makes stay within 8 per CU (half of what is resident at once): fewer envs per wave then,
+// i.e. a shorter divergent chain per wave (0_the_split at 4 096 envs: 2 -> 8 lanes, 0.0312 -> 0.0280 ms per env-step; the whole
+// table, every width at 4 096 .. 131 072 envs of both workloads: profiles/r05_step_lanes_sweep.txt).  Results do not depend on it.
 static int step_lanes(const DevCfg& cfg) {
     const int mo = cfg.n_opp[0] > cfg.n_opp[1] ? cfg.n_opp[0] : cfg.n_opp[1];
     int w = mo <= 1 ? 1 : (mo <= 2 ? 2 : (mo <= 4 ? 4 : 8));
-    while (w < 8 && (long long)cfg.n_envs * w / WAVE < 2LL * cfg.n_cus) w *= 2;
+    while (w < 8 && (long long)cfg.n_envs * (2 * w) / WAVE <= 8LL * cfg.n_cus) w *= 2;
     if (cfg.step_lanes_override) w = cfg.step_lanes_override;  // profiling / test knob (CTF_STEP_W)
     return w;
 }
@@ -1424,7 +1429,8 @@ extern "C" hipError_t ctf_launch_observe(const DevCfg& cfg, const DevPtrs& p, ui
         const size_t sh = (size_t)wpb * tiles_wave_bytes(cfg.RS, cfg.N, cfg.M);
         const char* xenv = getenv("CTF_OBS_XCD");  // 0: launch-order tiles (profiling); default: XCD-contiguous
         const uint32_t xcd_map = xenv ? (atoi(xenv) != 0) : 1u;
-        hipLaunchKernelGGL(k_observe_tiles, dim3((unsigned)cfg.tile_nb), dim3(wpb * WAVE), sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
+        if (cfg.obs_store_nt) hipLaunchKernelGGL(k_observe_tiles<1>, dim3((unsigned)cfg.tile_nb), dim3(wpb * WAVE), sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
+        else hipLaunchKernelGGL(k_observe_tiles<0>, dim3((unsigned)cfg.tile_nb), dim3(wpb * WAVE), sh, st, cfg, p, obs, meta, reverse_mask, xcd_map);
         return hipGetLastError();
     }
     // waves per block: 4 unless one env's bitmap is so large that 4 of them would crowd the CU's LDS

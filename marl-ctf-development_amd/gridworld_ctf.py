@@ -136,7 +136,7 @@ class VecGridworldCtf:
                                          device=self.device)
         return self._codes
 
-    def _tune_obs_placement(self, good_enough=1.06):
+    def _tune_obs_placement(self, good_enough=1.0):
         """Keep the candidate allocation the render streams into fastest (see __init__).
 
         BOUNDED in what it HOLDS: one candidate beside the best one so far — two observation buffers, 3.3 GB for the arena batch —
@@ -148,8 +148,9 @@ class VecGridworldCtf:
         CTF_PLACEMENT_TRIES) at a few milliseconds each.  An allocation failure ends the search with what it has.
 
         The search stops at a candidate whose render takes at most ``good_enough`` x the time of a plain ``fill_`` of the same
-        buffer (which does not depend on the buffer's kind), or — once it holds one of the fast kind (render / fill <= 1.12: the kinds
-        form two clusters, 1.02-1.12 and 1.19-1.27, the fill itself 0.234-0.245 ms from box to box) — when
+        buffer (which does not depend on the buffer's kind), or — once it holds one of the fast kind (render / fill <= 1.08: with the
+        render's nontemporal stores the kinds lie at 1.02-1.07 and 1.15-1.26 for the 15 x 15 arena, from 0.95 in a continuum for the
+        20 x 20 one, the fill itself 0.234-0.245 ms from box to box; profiles/r05_render_nontemporal.md) — when
         ``placement_seconds`` of wall time are used up; ten seconds while it holds none.  ``self.placement`` says what was found."""
         import time
 
@@ -179,15 +180,15 @@ class VecGridworldCtf:
         best_ms = probe(best)
         times = [best_ms]
         fill_ms = timed(lambda: best.fill_(0))
-        # Once a buffer of the good cluster is in hand the search goes on for its BEST members — the cluster itself spans render / fill
-        # 1.04-1.10 (0.246-0.264 ms on the arena; round 5: one box's two runs kept 0.2614 and 0.2497 = 199 and 207 M env-steps/s) and a
+        # Once a buffer of the good cluster is in hand the search goes on for its BEST members — the cluster itself spans 5 % of the
+        # render's time (round 5, plain stores: one box's two runs kept 0.2614 and 0.2497 ms = 199 and 207 M env-steps/s) and a
         # candidate costs 1.5 ms — until one is good enough, the tries are used up, or `placement_seconds` (default 3.0;
         # CTF_PLACEMENT_SECONDS) have gone by (3.3 times that, i.e. ten seconds by default, while no buffer of the fast kind has turned up at all).  (Round 3's rule — eight more tries — found a second good one 4 times in 10.)
         for _ in range(tries - 1):
             if best_ms <= good_enough * fill_ms:
                 break
             elapsed = time.perf_counter() - t0
-            in_hand = best_ms <= 1.12 * fill_ms  # a buffer of the fast kind (the relative test of round 3 — 7 % under the slowest seen —
+            in_hand = best_ms <= 1.08 * fill_ms  # a buffer of the fast kind (the relative test of round 3 — 7 % under the slowest seen —
                                                  # misfires on one outlier: a slow-only box stopped at 1.19 after 3.7 s)
             if (in_hand and elapsed > self._placement_seconds) or elapsed > min(10.0, 3.3 * self._placement_seconds):
                 break  # (the second bound: a box that hands out slow allocations only — one in six to thirteen fresh boxes; at 50 ms a
@@ -208,7 +209,7 @@ class VecGridworldCtf:
         ratio = best_ms / fill_ms
         self.placement_probe_ms = times
         self.placement_fill_ms = fill_ms
-        self.placement = dict(kind="fast" if ratio <= 1.10 else ("intermediate" if ratio <= 1.16 else "slow"), render_over_fill=ratio,
+        self.placement = dict(kind="fast" if ratio <= 1.08 else ("intermediate" if ratio <= 1.14 else "slow"), render_over_fill=ratio,
                               render_ms=best_ms, fill_ms=fill_ms, candidates=len(times), slowest_candidate_render_ms=max(times),
                               peak_held_bytes=min(len(times), 2) * nbytes, searched_bytes=len(times) * nbytes,
                               search_ms=(time.perf_counter() - t0) * 1e3)

@@ -44,7 +44,7 @@ for i, flags in enumerate(sys.argv[1:]):
     if os.environ.get("AB_BUILD_ONLY"):
         continue
     os.environ.update(ENVS[full])  # variables that are read when the handle is created (CTF_STEP_W)
-    vecs.append((full, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0 and not os.environ.get("AB_NOTUNE")), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_", "ctf_set_rng_states", "ctf_get_rng_states")), **kw)))
+    vecs.append((full, pkg.VecGridworldCtf(E, device=0, tune_placement=(i == 0 and not os.environ.get("AB_NOTUNE")), _lib=abi.bind(so, mode=ctypes.RTLD_LOCAL, optional=("ctf_policy_", "ctf_rollout_", "ctf_set_rng_states", "ctf_get_rng_states")), **kw)))
     for k in ENVS[full]:
         del os.environ[k]
 if os.environ.get("AB_BUILD_ONLY"):
