@@ -23,7 +23,7 @@ for key in "$@"; do
     split) tag=${ROUND}_split; wl=split_4096; args="--no-secondary --workload split --envs-per-gpu 4096";;
   esac
   PROFILE_BENCH_ARGS="$args" python3 tools/summarize_profile.py gpurun_out/prof_$tag $tag $wl || exit 1
-  cp profiles/${tag}_kernel_stats.csv profiles/${tag}_pmc_summary.json profiles/${tag}_bench_under_rocprof.json profiles/${tag}_PROVENANCE.txt gpurun_out/${ROUND}_summaries/
+  cp profiles/${tag}_kernel_stats.csv profiles/${tag}_pmc_summary.json profiles/${tag}_bench_under_rocprof.json profiles/${tag}_PROVENANCE.txt profiles/${tag}_timed_region_kernels.json gpurun_out/${ROUND}_summaries/
   rm -rf gpurun_out/prof_$tag
 done
 cp profiles/traffic.json gpurun_out/${ROUND}_summaries/

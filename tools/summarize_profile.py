@@ -66,13 +66,53 @@ def main():
         lines = [l for l in open(tlog, errors="replace") if l.startswith('{"metric"')]
         if lines:
             open(os.path.join(root, tag + "_bench_under_rocprof.json"), "w").write(lines[-1])
+    # the same launches bench.py timed: the last `windows x steps` launches of the step and render kernels before the 12 sampled
+    # steps at the end of the process, from the kernel trace — the average to hold against the line's kernels_ms and ms_per_step
+    timed_note = ""
+    ktrace = one(os.path.join(src, "trace", "**", "*_kernel_trace.csv"))
+    bpath = os.path.join(root, tag + "_bench_under_rocprof.json")
+    if ktrace and os.path.exists(bpath) and "policy" not in tag:
+        line = json.loads(open(bpath).read())
+        n_timed = int(line["steps"]) * len(line.get("windows_ms_per_step", [0]))
+        n_sample = 12  # bench.py: SAMPLE_STEPS
+        per = defaultdict(list)
+        with open(ktrace, newline="") as f:
+            for r in csv.DictReader(f):
+                k = r["Kernel_Name"]
+                if "k_step<" in k or ("k_observe" in k and "codes" not in k):
+                    per[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        timed = {}
+        for v in per.values():
+            v.sort()
+        # the render delimits the region (nothing launches it after the sampled steps); k_step also runs in what follows them
+        renders = [k for k in per if "k_observe" in k]
+        render = max(renders, key=lambda k: len(per[k])) if renders else None
+        if render and len(per[render]) > n_timed + n_sample:
+            rv = per[render]
+            t_lo, t_hi = rv[len(rv) - n_sample - n_timed - 1][1], rv[len(rv) - n_sample - 1][1]
+            for k, v in per.items():
+                w = [(s_, e) for s_, e in v if t_lo <= s_ < t_hi]
+                if not w:
+                    continue
+                timed[k] = dict(launches=len(w), avg_ns=sum(e - s_ for s_, e in w) / len(w), all_launches=len(v),
+                                all_avg_ns=sum(e - s_ for s_, e in v) / len(v))
+            timed["_region"] = dict(launches=n_timed, avg_ns=(t_hi - t_lo) / n_timed, all_launches=n_timed, all_avg_ns=(t_hi - t_lo) / n_timed)
+        if timed:
+            json.dump(dict(source=tag, note="rocprofv3 --kernel-trace: the launches of bench.py's timed windows only (the last "
+                           f"{n_timed} before the {n_sample} sampled steps that end the process); all_avg_ns = every launch of the process, placement search included",
+                           bench_kernels_ms=line.get("kernels_ms"), bench_ms_per_step=line.get("ms_per_step"), kernels=timed),
+                      open(os.path.join(root, tag + "_timed_region_kernels.json"), "w"), indent=1, sort_keys=True)
+            timed_note = ("  " + tag + "_timed_region_kernels.json: the trace's averages over the timed windows' launches alone: "
+                          + "; ".join(f"{k.split('(')[0].replace('void ', '')} {v['avg_ns'] / 1e6:.4f} ms x {v['launches']}" for k, v in sorted(timed.items()))
+                          + " (_region: first timed launch's predecessor's end to the last one's end, per step; the windows' host-side joins included).")
     script = "tools/profile_policy.sh" if "policy" in tag else "tools/profile.sh"
     with open(os.path.join(root, tag + "_PROVENANCE.txt"), "w") as f:
         f.write(f"{tag}_kernel_stats.csv, {tag}_pmc_summary.json, {tag}_bench_under_rocprof.json: one invocation of `bash {script} {tag}` on one MI355X box "
                 f"(BENCH_ARGS={os.environ.get('PROFILE_BENCH_ARGS', 'see the script')}); passes found: "
                 + ", ".join(p for p in ("trace", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3") if os.path.isdir(os.path.join(src, p)))
                 + ".  kernel_stats averages run over ALL launches of the process (stagger phase, warm-up and secondaries included); the bench line's "
-                  "kernels_ms are HIP events around the two launches of 12 steps run AFTER the timed windows, net of an empty event pair.\n")
+                  "kernels_ms are HIP events around the two launches of 12 steps run AFTER the timed windows, net of an empty event pair."
+                + timed_note + "\n")
     out = {}
     for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
         path = one(os.path.join(src, p, "**", "*_counter_collection.csv"))
