@@ -197,9 +197,10 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  *   reverse_mask bit i = reverse_grid for agent i; CTF_REVERSE_DEFAULT = (team(i) == 1), the value
  *                every caller in the reference passes (ppo.py:69,87; utils.py:535)
  * One launch: k_observe_tiles (one wave per 8 KiB of the flat buffer) when an env's block is a multiple of 16 bytes and at
- * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way.  The tile
- * kernel's stores carry the nontemporal hint (the observations pass by the caches, which keep the env state for the next step;
- * CTF_OBS_NT=0 at ctf_create: plain stores) — a consumer reads them from HBM either way: they are far larger than any cache.
+ * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way.  When the
+ * batch's observations exceed 320 MB (more than the caches absorb) the tile kernel's stores carry the nontemporal hint: the
+ * observations pass by the caches, which keep the env state for the next step (CTF_OBS_NT=0 / 1 at ctf_create forces plain /
+ * hinted stores); a smaller batch's observations are left in the memory-side cache for their consumer.
  *
  * PLACEMENT of obs_dev (the caller's buffer, so the caller's business): on MI355X roughly one hipMalloc allocation
  * of > 1 GiB in ten is of a kind this launch streams into at 0.87 of the HBM peak, the others cost it 15-20 % — a property of the

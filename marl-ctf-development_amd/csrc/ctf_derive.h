@@ -172,10 +172,14 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
             if (v >= 1 && v <= d->rng_spread) d->rng_spread = v;
         }
     }
-    // the tile render's stores carry the nontemporal hint: 1.65 GB of observations per launch then pass by the caches instead of
-    // sweeping the 88 MB of grids, records and digest windows out of them that the next k_step (and the render itself) reads —
-    // k_step 0.067 -> 0.059 ms, the render 0.251 -> 0.248 ms on the same buffer (profiles/r05_render_nontemporal.md).  CTF_OBS_NT=0: plain.
-    d->obs_store_nt = 1;
+    // The tile render's stores carry the nontemporal hint when the batch's observations are larger than the caches can absorb
+    // (the memory-side cache holds 256 MB): 1.65 GB per launch then pass by instead of sweeping out the 88 MB of grids, records and
+    // digest windows that the next k_step (and the render itself) reads — k_step 0.067 -> 0.059 ms, the render 0.251 -> 0.248 ms on
+    // the same buffer.  A smaller batch's observations stay in that cache and the hint only forces them out to HBM.  Measured
+    // crossover, plain -> hint in M env-steps/s (profiles/r05_render_nontemporal.md): arena 10 240 envs (258 MB) 149 -> 131, 11 264
+    // (284 MB) 145 -> 137, 12 288 (310 MB) 140 -> 141, 14 336 (361 MB) 137 -> 147; 20x20: 6 144 envs (275 MB) 82 -> 74, 8 192
+    // (367 MB) 80 -> 82.  Hence 320 MB.  CTF_OBS_NT=0 / 1 forces it off / on.
+    d->obs_store_nt = (int64_t)n_envs * d->obs_bytes > ((int64_t)320 << 20);
     if (const char* ov = getenv("CTF_OBS_NT")) d->obs_store_nt = atoi(ov) != 0;
     if (const char* ov = getenv("CTF_STEP_W")) {
         const int w = atoi(ov);

@@ -58,7 +58,7 @@ struct DevCfg {
     int32_t rng_spread;             // a stale ring is regenerated within this many launches of being seen: a burst of them (the
                                     // envs' positions move in step) is spread over as many launches by the rings' ages (rngage)
     int32_t n_cus;                  // compute units of the device (launch shapes)
-    int32_t obs_store_nt;           // 1 (default; CTF_OBS_NT=0 turns it off): k_observe_tiles stores with the nontemporal hint
+    int32_t obs_store_nt;           // k_observe_tiles stores with the nontemporal hint: when the batch's observations exceed 320 MB (CTF_OBS_NT=0 / 1 forces)
     // np.random.rand() < TAG_PROBABILITY on the 53-bit integer x = (a >> 5) * 2^26 + (b >> 6): x < tag_thr, split at bit 26
     uint32_t tag_th, tag_tl;
     int32_t np_pairs;               // rand() draws of one step without respawns: sum over the agents that deal damage of their opponents

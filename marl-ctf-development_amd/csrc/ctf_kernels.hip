@@ -958,7 +958,7 @@ __host__ __device__ inline int tiles_wave_bytes(int RS, int N, int M) {
     return OBS_TILE / 8 + RS + OBS_MV_BYTES + obs_meta_stage_bytes(N, M);
 }
 
-template <int STORE_NT>  // 1 (default, ctf_derive.h): the tile's stores carry the nontemporal hint and pass by the caches
+template <int STORE_NT>  // 1 (batches whose observations exceed the memory-side cache, ctf_derive.h): the tile's stores carry the nontemporal hint
 __global__ void __launch_bounds__(CTF_OBS_TILE_WPB * 64) k_observe_tiles(DevCfg cfg, DevPtrs p, uint8_t* __restrict__ obs, uint16_t* __restrict__ meta,
                                                        uint32_t reverse_mask, uint32_t xcd_map) {
     extern __shared__ uint32_t lds[];

@@ -19,11 +19,15 @@ kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii) if WORK
     dict(pkg.configs.ARENA20_KWARGS, SCENARIO=pkg.configs.arena20_scenario())
 seeds = np.arange(E, dtype=np.uint64) + 11
 vecs = {}
-for nt in (0, 1):
-    os.environ["CTF_OBS_NT"] = str(nt)
+for nt in (0, 1, "auto"):
+    if nt == "auto":
+        os.environ.pop("CTF_OBS_NT", None)
+    else:
+        os.environ["CTF_OBS_NT"] = str(nt)
     vecs[nt] = pkg.VecGridworldCtf(E, device=0, py_seeds=seeds, np_seeds=seeds, log_metrics=True, tune_placement=(TUNE and nt == 0), **kw)
 _ = vecs[0].obs  # the placement search runs here
 vecs[1].obs = vecs[0].obs
+vecs["auto"].obs = vecs[0].obs
 print(WORKLOAD, E, "envs; placement", vecs[0].placement, flush=True)
 dev = vecs[0].device
 table = torch.empty((8, E, 8), dtype=torch.int8, device=dev)
@@ -52,10 +56,10 @@ def window(vec, reps=100):
     return st, ob, a.elapsed_time(b) / reps
 
 
-for nt in (0, 1):
+for nt in (0, 1, "auto"):
     for _ in range(2):
         window(vecs[nt], 50)
 for rnd in range(4):
-    for nt in (0, 1):
+    for nt in (0, 1, "auto"):
         st, ob, whole = window(vecs[nt])
         print(f"round {rnd} CTF_OBS_NT={nt}: k_step {st:.4f} ms  render {ob:.4f} ms (raw events)  step_observe {whole:.4f} ms = {E / whole / 1e3:.1f} M env-steps/s", flush=True)
