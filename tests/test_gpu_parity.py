@@ -162,6 +162,31 @@ def test_batch_matches_oracle(name, n_envs, steps, log_metrics, tiles, monkeypat
     vec.close()
 
 
+def test_hinted_render_stores_write_the_same_bytes(monkeypatch):
+    """The tile render stores with the nontemporal hint when a batch's observations exceed 320 MB (ctf_derive.h: obs_store_nt) — the
+    full-size digest tests run that variant, everything smaller the plain one.  Here both at one size, forced by CTF_OBS_NT: the
+    same observation and metadata bytes every step (and the plain variant is compared with the oracle all over this file)."""
+    case = Case("arena_random")
+    n_envs = 1300
+    seeds = np.arange(n_envs, dtype=np.uint64) * 13 + 1
+    vecs = []
+    for nt in ("0", "1"):
+        monkeypatch.setenv("CTF_OBS_NT", nt)
+        vecs.append(pkg.VecGridworldCtf(n_envs, device=_dev(), py_seeds=seeds, np_seeds=seeds, tune_placement=False, **case.kwargs))
+    assert all(v.observe_kernel() == "k_observe_tiles" for v in vecs)
+    acts = torch.empty((n_envs, case.n), dtype=torch.int8, device=vecs[0].device)
+    for t in range(24):
+        vecs[0].random_actions(acts, seed=77, step=t)
+        outs = [v.step_observe(acts, auto_reset=True) for v in vecs]
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b), f"step {t}"
+        if t % 6 == 0:  # a non-default reversal mask now and then
+            o = [v.observe(reverse_mask=0b10100110)[0].clone() for v in vecs]
+            assert torch.equal(o[0], o[1]) and o[0].any()
+    for v in vecs:
+        v.close()
+
+
 @pytest.mark.parametrize("name", ["arena_stress", "split_random", "syn_edge_k1"])
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8])
 def test_every_step_lane_width_matches_the_oracle(name, lanes, monkeypatch):
