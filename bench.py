@@ -328,6 +328,7 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     if stagger:
         stagger_phases(vec, torch, lo, kwargs["GAME_STEPS"])
     observe_kernel = vec.observe_kernel()  # the library's own answer for this buffer (ctf_observe_kernel)
+    observe_stores = vec.observe_stores()  # "nontemporal" for batches whose observations exceed the caches (ctf_observe_stores_hinted)
 
     def one_step(i, t):
         if gather is not None:
@@ -379,7 +380,7 @@ def run_workload(pkg, torch, name, E, K, W, rank, local_rank, world, run, log_me
     obs_raw = np.array([e[1].elapsed_time(e[2]) for e in ev])
     step_all, obs_all = np.maximum(step_raw - pair, 0.0), np.maximum(obs_raw - pair, 0.0)
     out = dict(name=name, label=label, E=E, N=N, G=G, C=C, K=K, W=W, windows=win, env_lo=lo, status=status | vec.status(),
-               observe_kernel=observe_kernel,
+               observe_kernel=observe_kernel, observe_stores=observe_stores,
                k_step_ms=float(step_all.mean()), k_observe_ms=float(obs_all.mean()),
                k_step_raw_ms=float(step_raw.mean()), k_observe_raw_ms=float(obs_raw.mean()), event_pair_ms=pair,
                k_step_p=[float(x) for x in np.percentile(step_all, [10, 50, 90])],
@@ -420,7 +421,7 @@ def dryrun_workload(pkg, name, E, K, W, rank, dist, windows=5, env_lo=None):
             dist.barrier()
     return dict(name=name, label=label, E=E, N=cfg.n_agents, G=cfg.grid_size, C=cfg.n_channels, K=K, W=W, windows=win,
                 env_lo=rank * E if env_lo is None else env_lo, status=0,
-                observe_kernel="none (dry run)", k_step_ms=0.25, k_observe_ms=0.75, k_step_raw_ms=0.25, k_observe_raw_ms=0.75,
+                observe_kernel="none (dry run)", observe_stores="none (dry run)", k_step_ms=0.25, k_observe_ms=0.75, k_step_raw_ms=0.25, k_observe_raw_ms=0.75,
                 event_pair_ms=0.0, k_step_p=[0.25] * 3, k_observe_p=[0.75] * 3,
                 kernel_timing_samples=0, placement_probe_ms=None, placement_fill_ms=None, placement=None, kwargs=kwargs)
 
@@ -445,6 +446,7 @@ def workload_block(r, value, traffic_table, n_gpus=1):
         "roofline": roofline_of(r, traffic_table),
         "whole_step_hbm_frac": env_step_algorithmic_bytes(N, C, G) * value / n_gpus / 1e9 / HBM_PEAK_GBS,
         "kernels_ms": {"k_step": r["k_step_ms"], r["observe_kernel"]: r["k_observe_ms"]},
+        "render_stores": r["observe_stores"],
         "kernels_ms_raw_events": {"k_step": r["k_step_raw_ms"], r["observe_kernel"]: r["k_observe_raw_ms"]},
         "event_pair_overhead_ms": r["event_pair_ms"],
         "kernels_ms_p10_p50_p90": {"k_step": r["k_step_p"], r["observe_kernel"]: r["k_observe_p"]},
@@ -616,7 +618,7 @@ def main():
             },
         }
         blk = workload_block(r, value, traffic_table, n_gpus)
-        for k in ("windows", "windows_ms_per_step", "roofline", "whole_step_hbm_frac", "kernels_ms", "kernels_ms_raw_events",
+        for k in ("windows", "windows_ms_per_step", "roofline", "whole_step_hbm_frac", "kernels_ms", "render_stores", "kernels_ms_raw_events",
                   "event_pair_overhead_ms", "kernels_ms_p10_p50_p90", "kernel_timing_samples", "kernel_timing"):
             line[k] = blk[k]
         line.update({

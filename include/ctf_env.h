@@ -216,6 +216,9 @@ int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t rev
 /* which of the two a ctf_observe into obs_dev launches: 1 = k_observe_tiles, 0 = k_observe (profiling: attributing a measured
  * duration to the right kernel) */
 int32_t ctf_observe_kernel(const ctf_env* env, const uint8_t* obs_dev);
+/* 1 when that launch stores the observation with the nontemporal hint (the tile kernel on a batch whose observations exceed
+ * 320 MB, or CTF_OBS_NT=1), 0 for plain stores */
+int32_t ctf_observe_stores_hinted(const ctf_env* env, const uint8_t* obs_dev);
 
 /* The same observation in compact form: the tile planes 1..C-1 of standardise_state are one-hot per cell
  * (plane k+1 = (relabelled grid == TILES_USED[k]), gridworld_ctf.py:990-1001) and plane 0 holds the single

@@ -125,6 +125,7 @@ SYMBOLS = {
     "ctf_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_observe": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
     "ctf_observe_kernel": (C.c_int32, [_P, _P]),
+    "ctf_observe_stores_hinted": (C.c_int32, [_P, _P]),
     "ctf_observe_codes": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P]),
     "ctf_step_observe": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P]),
     "ctf_action_mask": (C.c_int, [_P, _P]),

@@ -333,6 +333,11 @@ extern "C" int32_t ctf_observe_kernel(const ctf_env* h, const uint8_t* obs) {
     return ctf_observe_uses_tiles(h->d, obs) ? 1 : 0;
 }
 
+extern "C" int32_t ctf_observe_stores_hinted(const ctf_env* h, const uint8_t* obs) {
+    if (!h) return -1;
+    return ctf_observe_uses_tiles(h->d, obs) && h->d.obs_store_nt ? 1 : 0;
+}
+
 extern "C" int ctf_observe_codes(ctf_env* h, uint8_t* codes, uint16_t* meta, uint16_t* selfcells, uint32_t reverse_mask, void* stream) {
     if (!h) return fail(CTF_E_INVALID, "null handle");
     if (!codes && !meta && !selfcells) return CTF_OK;

@@ -136,7 +136,7 @@ class VecGridworldCtf:
                                          device=self.device)
         return self._codes
 
-    def _tune_obs_placement(self, good_enough=1.0):
+    def _tune_obs_placement(self, good_enough=0.95):
         """Keep the candidate allocation the render streams into fastest (see __init__).
 
         BOUNDED in what it HOLDS: one candidate beside the best one so far — two observation buffers, 3.3 GB for the arena batch —
@@ -148,7 +148,8 @@ class VecGridworldCtf:
         CTF_PLACEMENT_TRIES) at a few milliseconds each.  An allocation failure ends the search with what it has.
 
         The search stops at a candidate whose render takes at most ``good_enough`` x the time of a plain ``fill_`` of the same
-        buffer (which does not depend on the buffer's kind), or — once it holds one of the fast kind (render / fill <= 1.08: with the
+        buffer (which does not depend on the buffer's kind; 0.95 is the very top of what any workload has shown, so in practice the
+        time limit ends the search: stopping at 1.00 cost the 20 x 20 map 5-8 % when the first candidate under it was a 0.99), or — once it holds one of the fast kind (render / fill <= 1.08: with the
         render's nontemporal stores the kinds lie at 1.02-1.07 and 1.15-1.26 for the 15 x 15 arena, from 0.95 in a continuum for the
         20 x 20 one, the fill itself 0.234-0.245 ms from box to box; profiles/r05_render_nontemporal.md) — when
         ``placement_seconds`` of wall time are used up; ten seconds while it holds none.  ``self.placement`` says what was found."""
@@ -310,6 +311,11 @@ class VecGridworldCtf:
     def observe_kernel(self):
         """Which kernel ``observe`` launches for this object's buffer: "k_observe_tiles" or "k_observe" (the library's own rule)."""
         return "k_observe_tiles" if self._lib.ctf_observe_kernel(self._h, C.c_void_p(self.obs.data_ptr())) == 1 else "k_observe"
+
+    def observe_stores(self):
+        """"nontemporal" when ``observe`` streams this object's buffer past the caches (the tile kernel on a batch whose observations
+        exceed 320 MB), else "plain"."""
+        return "nontemporal" if self._lib.ctf_observe_stores_hinted(self._h, C.c_void_p(self.obs.data_ptr())) == 1 else "plain"
 
     def observe_codes(self, reverse_mask=None, codes=True, meta=True):
         """The observation in compact form -> (codes uint8 [E, N, G, G], meta float16 [E, N, 2N+6]): low 7 bits = the tile
