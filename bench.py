@@ -297,6 +297,64 @@ def stagger_phases(vec, torch, lo, period=500):
     torch.cuda.synchronize()
 
 
+def two_shards_two_streams(pkg, torch, name, E, K, W, local_rank, run, windows=5, shards=2):
+    """The same E envs as `shards` handles of E / shards envs each (global env indices and seeds as in the headline), every handle's
+    own ctf_step_observe chain on its own HIP stream and NO synchronisation between the shards inside a window: one shard's k_step
+    runs beside the other's render.  What a caller gets that double-buffers its envs (each shard's policy step between that shard's
+    env steps) — not the headline's protocol, where one call steps all envs and the next call starts after it.  -> secondary block."""
+    sh = pkg.sharding
+    label, make_kwargs = WORKLOADS[name]
+    kwargs = make_kwargs(pkg)
+    device = torch.device("cuda", local_rank)
+    per = E // shards
+    vecs, acts, streams = [], [], []
+    for s in range(shards):
+        lo = s * per
+        seeds = sh.env_seeds(run, lo, lo + per)
+        v = pkg.VecGridworldCtf(per, device=local_rank, py_seeds=seeds, np_seeds=seeds, **kwargs)
+        v.observe()
+        stagger_phases(v, torch, lo, kwargs["GAME_STEPS"])
+        vecs.append(v)
+        acts.append(torch.empty((max(W, K), per, v.N_AGENTS), dtype=torch.int8, device=device))
+        streams.append(torch.cuda.Stream(device=device))
+
+    def fill(first, count):
+        for s, v in enumerate(vecs):
+            for i in range(count):
+                v.random_actions(acts[s][i], seed=0xC7F, step=first + i, env_offset=s * per)
+
+    def steps(count):
+        for i in range(count):
+            for v, a, st in zip(vecs, acts, streams):
+                with torch.cuda.stream(st):
+                    v.step_observe(a[i], auto_reset=True)
+
+    fill(0, W)
+    torch.cuda.synchronize()
+    steps(W)
+    t, win = W, []
+    for _ in range(max(1, windows)):
+        fill(t, K)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps(K)
+        torch.cuda.synchronize()
+        win.append(time.perf_counter() - t0)
+        t += K
+    status = 0
+    for v in vecs:
+        status |= v.status()
+    med = sorted(win)[len(win) // 2]
+    out = {"value": E * K / med, "unit": "env-steps/s", "steps": K, "windows": len(win), "ms_per_step": med / K * 1e3,
+           "windows_ms_per_step": [w / K * 1e3 for w in win], "shards": shards, "envs_per_shard": per,
+           "placement": [v.placement for v in vecs], "device_status_bits": status,
+           "protocol": f"{shards} handles x {per} envs on {shards} HIP streams, each stream its own K ctf_step_observe calls, no "
+                       "synchronisation between the shards inside a window (host wall clock around a window, synchronize on both sides)"}
+    for v in vecs:
+        v.close()
+    return out
+
+
 SAMPLE_STEPS = 12  # steps run AFTER the timed windows with an event around each launch (the per-kernel durations)
 
 
@@ -666,6 +724,12 @@ def main():
             bc = workload_block(rc, E * rc["K"] / rc["elapsed"], traffic_table)
             bc["workload"] = f"{rc['label']}, {E} envs, rng_mode=counter (Philox4x32-10 streams; parity: the oracle reading the same tape)"
             sec["arena_65536_counter_rng"] = bc
+            try:  # the headline's envs as two free-running shards on two streams (what a double-buffering caller gets); never the headline
+                b2s = two_shards_two_streams(pkg, torch, "arena", E, max(20, min(K, 100)), W, local_rank, args.run, args.windows)
+                b2s["workload"] = f"{r['label']}, {E} envs as 2 shards of {E // 2} on 2 HIP streams of one GPU"
+                sec["arena_65536_two_shards"] = b2s
+            except Exception as exc:  # a secondary must never cost the headline line
+                sec["arena_65536_two_shards"] = {"error": repr(exc)}
             try:  # the boundary's drop-in mode: the reference's own GridworldCtf API driven as ppo.py:59-98 drives it, one env
                 sec["facade_1env"] = facade_1env(pkg, r["kwargs"], local_rank)
             except Exception as exc:

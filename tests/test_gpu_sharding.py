@@ -71,3 +71,43 @@ def test_two_shards_equal_the_two_halves_of_one_batch(workload, n_global, rng_mo
         vec.close()
     assert whole.status() == 0
     whole.close()
+
+
+def test_free_running_shards_on_their_own_streams_equal_one_batch():
+    """bench.py's `secondary.arena_65536_two_shards`: two handles, each with its own HIP stream and its own chain of ctf_step_observe
+    calls, nothing synchronising them until the end — one shard's k_step runs beside the other's render.  Whatever the interleaving,
+    every shard ends where its envs end inside one batch stepped call by call: last observations, rewards, counters, generators."""
+    kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii, GAME_STEPS=40)
+    n_global, run, steps = 2 * 5000, 5, 96
+    make = lambda lo, hi: pkg.VecGridworldCtf(hi - lo, device=0, py_seeds=sh.env_seeds(run, lo, hi), np_seeds=sh.env_seeds(run, lo, hi),
+                                              log_metrics=True, tune_placement=False, **kw)
+    whole = make(0, n_global)
+    ranges = [sh.shard_range(n_global, r, 2) for r in range(2)]
+    shards = [make(lo, hi) for lo, hi in ranges]
+    dev, N = whole.device, whole.N_AGENTS
+    table = torch.empty((steps, n_global, N), dtype=torch.int8, device=dev)
+    for t in range(steps):
+        whole.random_actions(table[t], seed=0xC7F, step=t, env_offset=0)
+    for t in range(steps):
+        whole.step_observe(table[t], auto_reset=True, want_f64=True)
+    torch.cuda.synchronize(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in shards]
+    parts = [table[:, lo:hi].contiguous() for lo, hi in ranges]
+    torch.cuda.synchronize(dev)
+    for t in range(steps):
+        for vec, acts, st in zip(shards, parts, streams):
+            with torch.cuda.stream(st):
+                vec.step_observe(acts[t], auto_reset=True, want_f64=True)
+    torch.cuda.synchronize(dev)
+    m1, c1, s1 = whole.counters()
+    py1, np1 = whole.get_rng_states()
+    for (lo, hi), vec in zip(ranges, shards):
+        assert torch.equal(vec.obs, whole.obs[lo:hi]) and torch.equal(vec.meta.view(torch.int16), whole.meta[lo:hi].view(torch.int16))
+        assert torch.equal(vec.rewards64.view(torch.int64), whole.rewards64[lo:hi].view(torch.int64)) and torch.equal(vec.done, whole.done[lo:hi])
+        m2, c2, s2 = vec.counters()
+        assert torch.equal(m2, m1[lo:hi]) and torch.equal(c2, c1[lo:hi]) and torch.equal(s2, s1[lo:hi])
+        py2, np2 = vec.get_rng_states()
+        assert torch.equal(py2, py1[lo:hi]) and torch.equal(np2, np1[lo:hi])
+        assert vec.status() == 0
+        vec.close()
+    whole.close()
