@@ -1,7 +1,7 @@
 """One process, S handles of 65 536 / S envs each on S streams (every handle's own step -> render chain in order on its stream, the
 handles independent): does another shard's k_step fill the render's gaps now that the render's stores pass by the caches?  Four
 RANKS on one device read 224 M env-steps/s aggregate against 215 M for one handle (profiles/r05_four_ranks_one_gpu_bench.json).
-Usage: python tools/two_shards_overlap.py [total_envs]"""
+Usage: python tools/two_shards_overlap.py [total_envs] [all|free]"""
 import importlib
 import os
 import sys
@@ -104,9 +104,14 @@ def run(shards, join_every_step, reps=200):
 
 
 if __name__ == "__main__":
+    plan = sys.argv[2] if len(sys.argv) > 2 else "all"
     run(1, False)
-    run(2, "staggered")
-    run(4, "staggered")
+    if plan == "all":
+        run(2, "staggered")
+        run(4, "staggered")
+        run(2, True)
     run(2, False)
-    run(1, "staggered")
+    run(4, False)
+    if plan == "all":
+        run(1, "staggered")
     run(1, False)
