@@ -198,9 +198,10 @@ int ctf_step(ctf_env* env, const int8_t* actions_dev, float* rewards_f32_dev, do
  *                every caller in the reference passes (ppo.py:69,87; utils.py:535)
  * One launch: k_observe_tiles (one wave per 8 KiB of the flat buffer) when an env's block is a multiple of 16 bytes and at
  * least 8 KiB and obs_dev is 16-byte aligned, k_observe (one wave per env) otherwise; identical bytes either way.  When the
- * batch's observations exceed 320 MB (more than the caches absorb) the tile kernel's stores carry the nontemporal hint: the
- * observations pass by the caches, which keep the env state for the next step (CTF_OBS_NT=0 / 1 at ctf_create forces plain /
- * hinted stores); a smaller batch's observations are left in the memory-side cache for their consumer.
+ * observations of all live handles of this process on the device together exceed 320 MB (more than the caches absorb) the tile
+ * kernel's stores carry the nontemporal hint: the observations pass by the caches, which keep the env state for the next step
+ * (CTF_OBS_NT=0 / 1 at ctf_create forces plain / hinted stores; other PROCESSES' handles on the device are not seen); smaller
+ * batches' observations are left in the memory-side cache for their consumer.
  *
  * PLACEMENT of obs_dev (the caller's buffer, so the caller's business): on MI355X roughly one hipMalloc allocation
  * of > 1 GiB in ten is of a kind this launch streams into at 0.87 of the HBM peak, the others cost it 15-20 % — a property of the
@@ -216,8 +217,8 @@ int ctf_observe(ctf_env* env, uint8_t* obs_dev, uint16_t* meta_dev, uint32_t rev
 /* which of the two a ctf_observe into obs_dev launches: 1 = k_observe_tiles, 0 = k_observe (profiling: attributing a measured
  * duration to the right kernel) */
 int32_t ctf_observe_kernel(const ctf_env* env, const uint8_t* obs_dev);
-/* 1 when that launch stores the observation with the nontemporal hint (the tile kernel on a batch whose observations exceed
- * 320 MB, or CTF_OBS_NT=1), 0 for plain stores */
+/* 1 when that launch stores the observation with the nontemporal hint (the tile kernel while the live handles' observations on
+ * the device exceed 320 MB, or CTF_OBS_NT=1), 0 for plain stores */
 int32_t ctf_observe_stores_hinted(const ctf_env* env, const uint8_t* obs_dev);
 
 /* The same observation in compact form: the tile planes 1..C-1 of standardise_state are one-hot per cell

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,7 @@ struct ctf_env {
     // ctf_host_step (n_envs == 1): one pinned, device-mapped host block (allocated on first use) that the kernels read and write directly
     uint8_t* hio_dev;   // the DEVICE address of that block (hipHostGetDevicePointer)
     uint8_t* hio_host;  // its host address
+    int nt_override;    // CTF_OBS_NT at create: 0 / 1 force the render's store hint off / on, -1 = the rule (store_hint)
 };
 
 // Layout of the ctf_host_step block (byte offsets; every segment 16-byte aligned, the observation 256-byte aligned).
@@ -88,6 +90,19 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(CTF_E_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// The render's nontemporal store hint (ctf_derive.h has the why and the measured crossover) follows what ALL live handles of this
+// process on the device write per step, not one handle's share: four shards of 8 192 arena envs (206 MB each) stored plain read
+// 183 M env-steps/s, hinted 218 M — each fits the caches, the four together do not (profiles/r05_two_shards_overlap.md).  Other
+// PROCESSES on the device are not seen: CTF_OBS_NT=1 is for them.
+#define CTF_MAX_DEVICES 64
+static std::atomic<long long> g_obs_bytes[CTF_MAX_DEVICES];
+static long long obs_total(const ctf_env* h) { return (long long)h->d.n_envs * h->d.obs_bytes; }
+static int store_hint(const ctf_env* h) {
+    if (h->nt_override >= 0) return h->nt_override;
+    const long long all = h->device >= 0 && h->device < CTF_MAX_DEVICES ? g_obs_bytes[h->device].load(std::memory_order_relaxed) : obs_total(h);
+    return all > ((long long)320 << 20);
+}
+
 // remembers and restores the caller's current device
 struct DeviceGuard {
     int prev = -1;
@@ -133,6 +148,10 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
     h->rng_scratch = nullptr;
     h->hio_dev = nullptr;
     h->hio_host = nullptr;
+    {
+        const char* ov = getenv("CTF_OBS_NT");
+        h->nt_override = ov ? (atoi(ov) != 0) : -1;
+    }
     h->cfg = *cfg; h->d = d; h->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free_all(h); return fail(CTF_E_HIP, "hipGetDeviceProperties failed"); }
@@ -183,12 +202,14 @@ extern "C" int ctf_create(const ctf_config* cfg, int32_t n_envs, int32_t device_
         free_all(h);
         return fail(CTF_E_HIP, "first reset/seed failed: %s", hipGetErrorString(bad));
     }
+    if (device_id >= 0 && device_id < CTF_MAX_DEVICES) g_obs_bytes[device_id].fetch_add(obs_total(h), std::memory_order_relaxed);
     *out = h;
     return CTF_OK;
 }
 
 extern "C" void ctf_destroy(ctf_env* h) {
     if (!h) return;
+    if (h->device >= 0 && h->device < CTF_MAX_DEVICES) g_obs_bytes[h->device].fetch_sub(obs_total(h), std::memory_order_relaxed);
     DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
     free_all(h);
@@ -324,6 +345,7 @@ extern "C" int ctf_observe(ctf_env* h, uint8_t* obs, uint16_t* meta, uint32_t re
     if (!h) return fail(CTF_E_INVALID, "null handle");
     if (!obs && !meta) return CTF_OK;
     DeviceGuard guard(h->device);
+    h->d.obs_store_nt = store_hint(h);
     HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
     return CTF_OK;
 }
@@ -335,7 +357,7 @@ extern "C" int32_t ctf_observe_kernel(const ctf_env* h, const uint8_t* obs) {
 
 extern "C" int32_t ctf_observe_stores_hinted(const ctf_env* h, const uint8_t* obs) {
     if (!h) return -1;
-    return ctf_observe_uses_tiles(h->d, obs) && h->d.obs_store_nt ? 1 : 0;
+    return ctf_observe_uses_tiles(h->d, obs) && store_hint(h) ? 1 : 0;
 }
 
 extern "C" int ctf_observe_codes(ctf_env* h, uint8_t* codes, uint16_t* meta, uint16_t* selfcells, uint32_t reverse_mask, void* stream) {
@@ -354,8 +376,10 @@ extern "C" int ctf_step_observe(ctf_env* h, const int8_t* actions, float* rw32, 
     // the render, was built and measured in round 3: the render lost more than the step kernel gained — 189-191 M against 198 M
     // env-steps/s, profiles/r03_side_stream_ablation.md.)
     HIP_TRY(ctf_launch_step(h->d, h->p, actions, rw32, rw64, done, flags, 1, (hipStream_t)stream));
-    if (obs || meta)
+    if (obs || meta) {
+        h->d.obs_store_nt = store_hint(h);
         HIP_TRY(ctf_launch_observe(h->d, h->p, obs, meta, resolve_reverse(h, reverse_mask), h->n_cus, (hipStream_t)stream));
+    }
     return CTF_OK;
 }
 

@@ -178,7 +178,8 @@ static int derive(const ctf_config* c, int32_t n_envs, DevCfg* d) {
     // the same buffer.  A smaller batch's observations stay in that cache and the hint only forces them out to HBM.  Measured
     // crossover, plain -> hint in M env-steps/s (profiles/r05_render_nontemporal.md): arena 10 240 envs (258 MB) 149 -> 131, 11 264
     // (284 MB) 145 -> 137, 12 288 (310 MB) 140 -> 141, 14 336 (361 MB) 137 -> 147; 20x20: 6 144 envs (275 MB) 82 -> 74, 8 192
-    // (367 MB) 80 -> 82.  Hence 320 MB.  CTF_OBS_NT=0 / 1 forces it off / on.
+    // (367 MB) 80 -> 82.  Hence 320 MB.  CTF_OBS_NT=0 / 1 forces it off / on.  (This is one handle's own share; the library applies the
+    // rule to the sum over all live handles on the device — ctf_abi.hip: store_hint.)
     d->obs_store_nt = (int64_t)n_envs * d->obs_bytes > ((int64_t)320 << 20);
     if (const char* ov = getenv("CTF_OBS_NT")) d->obs_store_nt = atoi(ov) != 0;
     if (const char* ov = getenv("CTF_STEP_W")) {

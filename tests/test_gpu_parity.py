@@ -187,6 +187,32 @@ def test_hinted_render_stores_write_the_same_bytes(monkeypatch):
         v.close()
 
 
+def test_store_hint_follows_what_all_live_handles_on_the_device_write(monkeypatch):
+    """The hint is for observations the caches cannot absorb — all of them: two shards of 8 192 arena envs (206 MB each) are stored
+    plain one at a time and hinted while both are alive (ctf_abi.hip: store_hint); CTF_OBS_NT forces either way."""
+    import gc
+
+    monkeypatch.delenv("CTF_OBS_NT", raising=False)
+    gc.collect()  # handles earlier tests dropped without close()
+    kw = dict(pkg.configs.ARENA_KWARGS, SCENARIO=pkg.CtfScenarios.arena_iii)
+    a = pkg.VecGridworldCtf(8192, device=_dev(), py_seeds=np.arange(8192, dtype=np.uint64), np_seeds=np.arange(8192, dtype=np.uint64),
+                            tune_placement=False, **kw)
+    assert a.observe_kernel() == "k_observe_tiles" and a.observe_stores() == "plain"
+    b = pkg.VecGridworldCtf(8192, device=_dev(), py_seeds=np.arange(8192, dtype=np.uint64), np_seeds=np.arange(8192, dtype=np.uint64),
+                            tune_placement=False, **kw)
+    assert a.observe_stores() == "nontemporal" and b.observe_stores() == "nontemporal"
+    oa, ob = a.observe()[0], b.observe()[0]
+    assert torch.equal(oa, ob)  # (same seeds, no step yet: the same bytes through the hinted kernel as ...
+    b.close()
+    assert a.observe_stores() == "plain"
+    assert torch.equal(a.observe()[0], ob)  # ... through the plain one)
+    monkeypatch.setenv("CTF_OBS_NT", "1")
+    c = pkg.VecGridworldCtf(64, device=_dev(), py_seeds=np.arange(64, dtype=np.uint64), np_seeds=np.arange(64, dtype=np.uint64), **kw)
+    assert c.observe_stores() == "nontemporal"
+    c.close()
+    a.close()
+
+
 @pytest.mark.parametrize("name", ["arena_stress", "split_random", "syn_edge_k1"])
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8])
 def test_every_step_lane_width_matches_the_oracle(name, lanes, monkeypatch):
