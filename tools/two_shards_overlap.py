@@ -1,7 +1,7 @@
 """One process, S handles of 65 536 / S envs each on S streams (every handle's own step -> render chain in order on its stream, the
 handles independent): does another shard's k_step fill the render's gaps now that the render's stores pass by the caches?  Four
 RANKS on one device read 224 M env-steps/s aggregate against 215 M for one handle (profiles/r05_four_ranks_one_gpu_bench.json).
-Usage: python tools/two_shards_overlap.py [total_envs] [all|free]"""
+Usage: python tools/two_shards_overlap.py [total_envs] [all|free|graph]"""
 import importlib
 import os
 import sys
@@ -61,7 +61,36 @@ def run(shards, join_every_step, reps=200):
             for e in ends:
                 cur.wait_event(e)
 
+    graphs = []
+
+    def build_graphs():
+        """one hipGraph per action slot: shard s + 1's step behind shard s's step, each shard's render behind its own step — the fork
+        and the join are edges of the graph, not events between streams; a replay on the caller's stream is one call with exact semantics"""
+        cap = torch.cuda.Stream(device=dev)
+        for k in range(8):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):
+                prev = None
+                for v, t, st in zip(vecs, tabs, streams):
+                    st.wait_stream(cap)
+                    if prev is not None:
+                        st.wait_event(prev)
+                    with torch.cuda.stream(st):
+                        v.step(t[k], auto_reset=True)
+                        prev = torch.cuda.Event()
+                        prev.record(st)
+                        v.observe()
+                for st in streams:
+                    cap.wait_stream(st)
+            graphs.append(g)
+
     def steps(n):
+        if join_every_step == "graph":
+            if not graphs:
+                build_graphs()
+            for k in range(n):
+                graphs[k % 8].replay()
+            return
         if join_every_step == "staggered":
             return staggered(n)
         for k in range(n):
@@ -105,6 +134,13 @@ def run(shards, join_every_step, reps=200):
 
 if __name__ == "__main__":
     plan = sys.argv[2] if len(sys.argv) > 2 else "all"
+    if plan == "graph":
+        run(1, False)
+        run(2, "graph")
+        run(4, "graph")
+        run(1, "graph")
+        run(2, False)
+        sys.exit(0)
     run(1, False)
     if plan == "all":
         run(2, "staggered")
